@@ -1,0 +1,103 @@
+/* symode.h -- C ABI of libsymode_hip.so: the MI355X (gfx950) SINDy hot path.
+ *
+ * The reference (Rose-STL-Lab/symmetry-ode-discovery) has no FFI boundary: the hot path is
+ * Python calling torch ops.  Each entry point below replaces the torch-op sequence named in
+ * its comment (file:line of the reference) and is what a binding for that sequence would
+ * call (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless stated), row-major,
+ *     contiguous; nothing is allocated or freed inside the library;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued asynchronously on it, no call synchronises;
+ *   - return value: 0 = ok, < 0 = SYMODE_E_* argument error (nothing was launched),
+ *     > 0 = a hipError_t reported by the launch;
+ *   - `flags`: bit 0 = include_sine, bit 1 = include_exp (reference sindy.py:74-77);
+ *   - library column order: [1 | x_i | x_i x_j (i<=j) | (x_i x_j) x_k (i<=j<=k) | ... |
+ *     sin x_i | exp x_i]  (reference sindy.py:7-30, 68-77); orders 4-5 continue the nesting.
+ *   - batched entry points take `n_problems` independent (trajectory, seed) problems laid
+ *     out back to back: x[s] = x + s*n*d, xi[s] = xi + s*d*p, ...
+ */
+#ifndef SYMODE_H
+#define SYMODE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYMODE_FLAG_SINE 1
+#define SYMODE_FLAG_EXP 2
+
+#define SYMODE_OK 0
+#define SYMODE_E_UNSUPPORTED (-1) /* (d, order, flags) outside the compiled library set */
+#define SYMODE_E_NULLPTR (-2)
+#define SYMODE_E_BADSIZE (-3)
+#define SYMODE_E_WORKSPACE (-4) /* workspace missing or too small */
+#define SYMODE_E_ALIGN (-5)     /* pointer not 4-byte (fp32) / 8-byte (fp64) aligned */
+
+/* ABI version of this header (bumped on any signature change). */
+int symode_abi_version(void);
+const char* symode_error_string(int code);
+
+/* p = number of library columns; SYMODE_E_UNSUPPORTED if (d, order, flags) is not compiled in.
+ * replaces: SINDyRegression.get_term_num, sindy.py:179-189 */
+int symode_lib_size(int d, int order, int flags);
+
+/* Bytes of scratch the batched reductions need for (n_problems, n) at this library.
+ * The same buffer serves symode_loss_grad / symode_aug_gram / the symreg entry points. */
+size_t symode_workspace_bytes(int d, int order, int flags, long n_problems, long n);
+
+/* Theta(x) materialised: theta_out (n, p).
+ * replaces: SINDyRegression.eval_Theta_at, sindy.py:201-203 (term functions sindy.py:7-30) */
+int symode_theta(const float* x, long n, int d, int order, int flags, float* theta_out, void* stream);
+
+/* out (n, d) = Theta(x) @ (xi * mask)^T ; mask may be NULL (all ones). xi, mask: (d, p).
+ * replaces: SINDyRegression.forward, sindy.py:79-82 */
+int symode_forward(const float* x, long n, int d, int order, int flags, const float* xi, const float* mask,
+                   float* out, void* stream);
+
+/* Fused Theta-build + residual + MSE + gradient, never materialising Theta:
+ *   r = Theta(x) (xi*mask)^T - dx ;  loss[s] = inv_count * sum r^2 ;
+ *   grad[s] (d, p) = 2 * inv_count * (r^T Theta) * mask.
+ * inv_count = 1/(n*d) gives torch's MSELoss mean; a rank holding a shard passes
+ * 1/(n_global*d) and all-reduces (SUM) loss and grad.
+ * replaces: closure body train.py:663-664 + backward train.py:689 (and 789-790, 802). */
+int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, int d, int order, int flags,
+                     const float* xi, const float* mask, float inv_count, float* loss_out, float* grad_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* K explicit Euler steps x <- x + dt * Theta(x)(xi*mask)^T, out (n, d).
+ * replaces: odeint(regressor, x, t, dt, 'euler'), model_utils.py:233-238 (n_steps = int(t/dt)
+ * is computed by the caller). method: 0 = euler, 1 = rk4 (model_utils.py:241-247). */
+int symode_odeint(const float* x, long n, int d, int order, int flags, const float* xi, const float* mask,
+                  int n_steps, float dt, int method, float* out, void* stream);
+
+/* Augmented Gram matrix in fp64 (MFMA f64): A = [Theta(x) | dx] (n, p+d),
+ *   gram_out[s] (p+d, p+d) = A^T A   (row-major, both triangles filled).
+ * Every quantity of the ridge-augmented least-squares solve (sindy.py:261-288) and of the
+ * MSE closure is a function of this matrix; x is fixed for a whole run (train.py:626).
+ * replaces: the normal-equation content of solve_SINDy_one_step, sindy.py:250-315. */
+int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, int d, int order, int flags,
+                    double* gram_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* S1, linear-latent symmetry regulariser (train.py:502-507 with the intended [1]):
+ *   loss = sum_v sum_n || Xi_m J_Theta(z_n)(L_v z_n) - L_v Xi_m Theta(z_n) ||^2,
+ *   grad (d, p) = dloss/dxi (masked).  L: (n_gen, d, d). */
+int symode_symreg_linear(const float* z, long n, int d, int order, int flags, const float* xi, const float* mask,
+                         const float* L, int n_gen, float* loss_out, float* grad_out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* S4, reversed symmetry regulariser with (g(x), J_g(x)) precomputed once
+ * (model_utils.py:126-170; g and J_g do not depend on xi, model_utils.py:172-211):
+ *   loss = sum_g mean_{n,j} ( J_g(x_n) h(x_n) - h(g(x_n)) )^2,  h = Theta(.)(xi*mask)^T,
+ *   grad (d, p) = dloss/dxi (masked).  gx: (n_g, n, d), jgx: (n_g, n, d, d). */
+int symode_symreg_reversed(const float* x, const float* gx, const float* jgx, int n_g, long n, int d, int order,
+                           int flags, const float* xi, const float* mask, float* loss_out, float* grad_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYMODE_H */

@@ -1,0 +1,160 @@
+// C ABI of libsymode_hip.so (declarations and per-entry reference citations: include/symode.h).
+// Argument validation happens here, on the host, before anything is launched: a call that
+// returns a negative code has touched no device memory.
+#include <cstdint>
+
+#include "../../include/symode.h"
+#include "ops_table.hpp"
+
+using namespace symode;
+
+namespace {
+
+const LibOps* find_ops(int d, int order, int flags) {
+    if (order < 1 || order > MAX_ORDER || flags < 0 || flags > 3) return nullptr;
+    switch (d) {
+        case 1: return ops_d1(order, flags);
+        case 2: return ops_d2(order, flags);
+        case 3: return ops_d3(order, flags);
+        case 4: return ops_d4(order, flags);
+        default: return nullptr;
+    }
+}
+
+inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p % a) != 0; }
+
+// points per 16-byte chunk step (points.hpp, Chunk<D>::PPT)
+inline int ppt_for(int d) { return d == 2 ? 2 : d == 4 ? 1 : 4; }
+
+// scratch (in doubles) of the widest reduction for this library at (S, n)
+size_t workspace_doubles(const LibOps* ops, long S, long n) {
+    const int F = ops->p + ops->d;
+    const int T = (F + 15) / 16;
+    const size_t gram_partial = (size_t)(T * (T + 1) / 2) * 256;
+    const size_t nacc = 1 + (size_t)ops->d * ops->p;
+    const size_t g_red = (size_t)grid_x_for(n, S, 1);   // widest grid any reduction uses
+    const size_t a = (size_t)S * g_red * nacc;
+    const size_t b = (size_t)S * g_red * (BLOCK / WAVE) * gram_partial;
+    return a > b ? a : b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int symode_abi_version(void) { return 1; }
+
+const char* symode_error_string(int code) {
+    switch (code) {
+        case SYMODE_OK: return "ok";
+        case SYMODE_E_UNSUPPORTED: return "library (d, order, flags) not compiled into libsymode_hip";
+        case SYMODE_E_NULLPTR: return "null pointer argument";
+        case SYMODE_E_BADSIZE: return "bad size argument";
+        case SYMODE_E_WORKSPACE: return "workspace missing or too small";
+        case SYMODE_E_ALIGN: return "misaligned pointer";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown symode error";
+    }
+}
+
+int symode_lib_size(int d, int order, int flags) {
+    const LibOps* ops = find_ops(d, order, flags);
+    return ops ? ops->p : SYMODE_E_UNSUPPORTED;
+}
+
+size_t symode_workspace_bytes(int d, int order, int flags, long n_problems, long n) {
+    const LibOps* ops = find_ops(d, order, flags);
+    if (!ops || n_problems < 1 || n < 0) return 0;
+    return workspace_doubles(ops, n_problems, n) * sizeof(double);
+}
+
+#define SYMODE_GET_OPS()                              \
+    const LibOps* ops = find_ops(d, order, flags);    \
+    if (!ops) return SYMODE_E_UNSUPPORTED;
+
+#define SYMODE_CHECK_WS(S_, n_)                                                              \
+    if (!workspace || misaligned(workspace, 8)) return SYMODE_E_WORKSPACE;                   \
+    if (workspace_bytes < workspace_doubles(ops, (S_), (n_)) * sizeof(double)) return SYMODE_E_WORKSPACE;
+
+int symode_theta(const float* x, long n, int d, int order, int flags, float* theta_out, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 0) return SYMODE_E_BADSIZE;
+    if (n == 0) return SYMODE_OK;
+    if (!x || !theta_out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(theta_out, 4)) return SYMODE_E_ALIGN;
+    return (int)ops->theta(x, n, theta_out, (hipStream_t)stream);
+}
+
+int symode_forward(const float* x, long n, int d, int order, int flags, const float* xi, const float* mask, float* out,
+                   void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 0) return SYMODE_E_BADSIZE;
+    if (n == 0) return SYMODE_OK;
+    if (!x || !xi || !out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(out, 4) || misaligned(xi, 4) || misaligned(mask, 4)) return SYMODE_E_ALIGN;
+    return (int)ops->forward(x, n, xi, mask, out, (hipStream_t)stream);
+}
+
+int symode_odeint(const float* x, long n, int d, int order, int flags, const float* xi, const float* mask, int n_steps,
+                  float dt, int method, float* out, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 0 || n_steps < 0 || (method != 0 && method != 1)) return SYMODE_E_BADSIZE;
+    if (n == 0) return SYMODE_OK;
+    if (!x || !xi || !out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(out, 4) || misaligned(xi, 4) || misaligned(mask, 4)) return SYMODE_E_ALIGN;
+    return (int)ops->odeint(x, n, xi, mask, n_steps, dt, method, out, (hipStream_t)stream);
+}
+
+int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, int d, int order, int flags,
+                     const float* xi, const float* mask, float inv_count, float* loss_out, float* grad_out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n_problems < 1 || n_problems > 65535 || n < 1) return SYMODE_E_BADSIZE;
+    if (!x || !dx || !xi || !loss_out || !grad_out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(loss_out, 4) ||
+        misaligned(grad_out, 4))
+        return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(n_problems, n);
+    const int gx = grid_x_for(n, n_problems, ppt_for(d));
+    return (int)ops->loss_grad(x, dx, n_problems, n, xi, mask, inv_count, loss_out, grad_out, (double*)workspace, gx,
+                               (hipStream_t)stream);
+}
+
+int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, int d, int order, int flags,
+                    double* gram_out, void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n_problems < 1 || n_problems > 65535 || n < 1) return SYMODE_E_BADSIZE;
+    if (!x || !dx || !gram_out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(n_problems, n);
+    const int gx = grid_x_for(n, n_problems, 1);
+    return (int)ops->aug_gram(x, dx, n_problems, n, gram_out, (double*)workspace, gx, (hipStream_t)stream);
+}
+
+int symode_symreg_linear(const float* z, long n, int d, int order, int flags, const float* xi, const float* mask,
+                         const float* L, int n_gen, float* loss_out, float* grad_out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 1 || n_gen < 0) return SYMODE_E_BADSIZE;
+    if (!z || !xi || !loss_out || !grad_out || (n_gen > 0 && !L)) return SYMODE_E_NULLPTR;
+    if (misaligned(z, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(L, 4)) return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(1, n);
+    const int gx = grid_x_for(n, 1, ppt_for(d));
+    return (int)ops->symreg_linear(z, n, xi, mask, L, n_gen, loss_out, grad_out, (double*)workspace, gx,
+                                   (hipStream_t)stream);
+}
+
+int symode_symreg_reversed(const float* x, const float* gx_, const float* jgx, int n_g, long n, int d, int order,
+                           int flags, const float* xi, const float* mask, float* loss_out, float* grad_out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 1 || n_g < 0) return SYMODE_E_BADSIZE;
+    if (!x || !xi || !loss_out || !grad_out || (n_g > 0 && (!gx_ || !jgx))) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(gx_, 4) || misaligned(jgx, 4) || misaligned(xi, 4) || misaligned(mask, 4))
+        return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(1, n);
+    const int gx = grid_x_for(n, 1, 1);
+    return (int)ops->symreg_reversed(x, gx_, jgx, n_g, n, xi, mask, loss_out, grad_out, (double*)workspace, gx,
+                                     (hipStream_t)stream);
+}
+
+}  // extern "C"

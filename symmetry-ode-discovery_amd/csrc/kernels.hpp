@@ -1,0 +1,496 @@
+// HIP kernels of the SINDy hot path, templated on the compile-time library description.
+// gfx950 only: 64-wide wavefronts, 256-thread workgroups (4 waves, one per SIMD).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "library.hpp"
+#include "points.hpp"
+#include "reduce.hpp"
+
+namespace symode {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_GRID_X = 2048;   // 256 CUs x 8 resident workgroups
+
+// One row of the dispatch table: everything the C ABI needs for one (D, ORDER, FLAGS).
+struct LibOps {
+    int d, order, flags, p;
+    hipError_t (*theta)(const float* x, long n, float* out, hipStream_t st);
+    hipError_t (*forward)(const float* x, long n, const float* xi, const float* mask, float* out, hipStream_t st);
+    hipError_t (*odeint)(const float* x, long n, const float* xi, const float* mask, int n_steps, float dt, int method,
+                         float* out, hipStream_t st);
+    hipError_t (*loss_grad)(const float* x, const float* dx, long S, long n, const float* xi, const float* mask,
+                            float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st);
+    hipError_t (*symreg_linear)(const float* z, long n, const float* xi, const float* mask, const float* L, int n_gen,
+                                float* loss, float* grad, double* ws, int gx, hipStream_t st);
+    hipError_t (*symreg_reversed)(const float* x, const float* gx_, const float* jgx, int n_g, long n, const float* xi,
+                                  const float* mask, float* loss, float* grad, double* ws, int gx, hipStream_t st);
+    hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, double* gram, double* ws, int gx,
+                           hipStream_t st);
+};
+
+// ---------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------
+
+// Grid width for a streaming pass over n points (per problem), S problems on grid.y.
+inline int grid_x_for(long n, long S, int pts_per_thread_iter) {
+    const long per_block = (long)BLOCK * pts_per_thread_iter * 4;   // >= 4 iterations per thread
+    long g = (n + per_block - 1) / per_block;
+    long cap = MAX_GRID_X / (S < 1 ? 1 : S);
+    if (cap < 2) cap = 2;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline bool vec_ok(const void* p, long n, int d, long S) {
+    return ((uintptr_t)p % 16 == 0) && (S == 1 || (n * d) % 4 == 0);
+}
+
+// Masked coefficients of problem s into registers (uniform across the block -> scalar loads).
+template <class Lib>
+__device__ __forceinline__ void load_xi(const float* __restrict__ xi, const float* __restrict__ mask, long s,
+                                        float (&w)[Lib::D * Lib::P]) {
+    constexpr int DP = Lib::D * Lib::P;
+    const float* a = xi + s * DP;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) w[i] = a[i];
+    if (mask != nullptr) {
+        const float* m = mask + s * DP;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) w[i] *= m[i];
+    }
+}
+
+// h = Theta . Xi_m^T for one point (fp32 fma chain over the library columns).
+template <class Lib>
+__device__ __forceinline__ void apply_xi(const float (&w)[Lib::D * Lib::P], const float (&th)[Lib::P],
+                                         float (&h)[Lib::D]) {
+#pragma unroll
+    for (int j = 0; j < Lib::D; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < Lib::P; ++k) s = fmaf(w[j * Lib::P + k], th[k], s);
+        h[j] = s;
+    }
+}
+
+template <class Lib>
+__device__ __forceinline__ void rhs(const float (&w)[Lib::D * Lib::P], const float (&x)[Lib::D], float (&h)[Lib::D]) {
+    float th[Lib::P];
+    Lib::eval(x, th);
+    apply_xi<Lib>(w, th, h);
+}
+
+// ---------------------------------------------------------------------------------------
+// Theta(x) materialised                                        (compat: eval_Theta_at)
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void theta_kernel(const float* __restrict__ x, long N, bool vec,
+                                                      float* __restrict__ out) {
+    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT;
+    auto one = [&](long n, const float (&xp)[D]) {
+        float th[P];
+        Lib::eval(xp, th);
+        float* o = out + n * P;
+#pragma unroll
+        for (int k = 0; k < P; ++k) o[k] = th[k];
+    };
+    for_each_point<D, BLOCK>(
+        N, vec,
+        [&](long c) {
+            float xp[PPT][D];
+            load_chunk<D>(x, c, xp);
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) one(c * PPT + i, xp[i]);
+        },
+        [&](long n) {
+            float xp[D];
+            load_point<D>(x, n, xp);
+            one(n, xp);
+        });
+}
+
+// ---------------------------------------------------------------------------------------
+// forward: out = Theta(x) Xi_m^T                               (regressor.forward)
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void forward_kernel(const float* __restrict__ x, long N, bool vec,
+                                                        const float* __restrict__ xi, const float* __restrict__ mask,
+                                                        float* __restrict__ out) {
+    constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
+    float w[D * Lib::P];
+    load_xi<Lib>(xi, mask, 0, w);
+    for_each_point<D, BLOCK>(
+        N, vec,
+        [&](long c) {
+            float xp[PPT][D], h[PPT][D];
+            load_chunk<D>(x, c, xp);
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) rhs<Lib>(w, xp[i], h[i]);
+            store_chunk<D>(out, c, h);
+        },
+        [&](long n) {
+            float xp[D], h[D];
+            load_point<D>(x, n, xp);
+            rhs<Lib>(w, xp, h);
+            store_point<D>(out, n, h);
+        });
+}
+
+// ---------------------------------------------------------------------------------------
+// fixed-step integrator: K Euler / RK4 steps of dx/dt = Theta(x) Xi_m^T   (odeint)
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__device__ __forceinline__ void integrate(const float (&w)[Lib::D * Lib::P], float (&x)[Lib::D], int n_steps, float dt,
+                                          int method) {
+    constexpr int D = Lib::D;
+    if (method == 0) {
+        for (int s = 0; s < n_steps; ++s) {
+            float h[D];
+            rhs<Lib>(w, x, h);
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[j] = x[j] + dt * h[j];               // model_utils.py:238
+        }
+    } else {
+        for (int s = 0; s < n_steps; ++s) {                                    // model_utils.py:242-247
+            float k1[D], k2[D], k3[D], k4[D], y[D];
+            rhs<Lib>(w, x, k1);
+#pragma unroll
+            for (int j = 0; j < D; ++j) y[j] = x[j] + dt / 2 * k1[j];
+            rhs<Lib>(w, y, k2);
+#pragma unroll
+            for (int j = 0; j < D; ++j) y[j] = x[j] + dt / 2 * k2[j];
+            rhs<Lib>(w, y, k3);
+#pragma unroll
+            for (int j = 0; j < D; ++j) y[j] = x[j] + dt * k3[j];
+            rhs<Lib>(w, y, k4);
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[j] = x[j] + dt / 6 * (k1[j] + 2 * k2[j] + 2 * k3[j] + k4[j]);
+        }
+    }
+}
+
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void odeint_kernel(const float* __restrict__ x, long N, bool vec,
+                                                       const float* __restrict__ xi, const float* __restrict__ mask,
+                                                       int n_steps, float dt, int method, float* __restrict__ out) {
+    constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
+    float w[D * Lib::P];
+    load_xi<Lib>(xi, mask, 0, w);
+    for_each_point<D, BLOCK>(
+        N, vec,
+        [&](long c) {
+            float xp[PPT][D];
+            load_chunk<D>(x, c, xp);
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) integrate<Lib>(w, xp[i], n_steps, dt, method);
+            store_chunk<D>(out, c, xp);
+        },
+        [&](long n) {
+            float xp[D];
+            load_point<D>(x, n, xp);
+            integrate<Lib>(w, xp, n_steps, dt, method);
+            store_point<D>(out, n, xp);
+        });
+}
+
+// ---------------------------------------------------------------------------------------
+// Reduction epilogue shared by every "scalar loss + (d,p) gradient" kernel.
+//   pass 1: each block leaves NACC fp64 partial sums in ws[(s*G + b)*NACC + k];
+//   pass 2: one block per problem adds the G partials in fixed order (deterministic),
+//           scales, masks, rounds to fp32.
+// ---------------------------------------------------------------------------------------
+template <int NACC>
+__device__ __forceinline__ void emit_partials(float (&acc)[NACC], double* __restrict__ ws) {
+    __shared__ float lds[(BLOCK / WAVE) * NACC];
+    double* dst = ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * NACC;
+    block_reduce_emit<NACC, BLOCK>(acc, lds, [&](int k, double v) { dst[k] = v; });
+}
+
+// out[0] = loss_scale * sum_0 ; grad[k-1] = grad_scale * sum_k * mask[k-1]
+// (a template only so that the header-defined kernel has vague linkage across the per-D TUs)
+template <int TAG = 0>
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restrict__ ws, int G, int nacc,
+                                                         const float* __restrict__ mask, float loss_scale,
+                                                         float grad_scale, float* __restrict__ loss,
+                                                         float* __restrict__ grad) {
+    const long s = blockIdx.x;
+    const double* src = ws + s * (long)G * nacc;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    for (int k = wave; k < nacc; k += BLOCK / WAVE) {
+        double v = 0.0;
+        for (int g = lane; g < G; g += WAVE) v += src[(long)g * nacc + k];
+        v = wave_sum(v);
+        if (lane == 0) {
+            if (k == 0) {
+                loss[s] = (float)(v * (double)loss_scale);
+            } else {
+                const long i = s * (nacc - 1) + (k - 1);
+                const float m = mask ? mask[i] : 1.0f;
+                grad[i] = (float)(v * (double)grad_scale) * m;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: fused Theta + residual + MSE + gradient                  (closure body + backward)
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
+                                                          long N, bool vec, const float* __restrict__ xi,
+                                                          const float* __restrict__ mask, double* __restrict__ ws) {
+    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NACC = 1 + D * P;
+    const long s = blockIdx.y;
+    const float* xs = x + s * N * D;
+    const float* ys = dx + s * N * D;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, s, w);
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+
+    auto one = [&](const float (&xp)[D], const float (&yp)[D]) {
+        float th[P], r[D];
+        Lib::eval(xp, th);
+        apply_xi<Lib>(w, th, r);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            r[j] -= yp[j];
+            acc[0] = fmaf(r[j], r[j], acc[0]);
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(r[j], th[k], acc[1 + j * P + k]);
+    };
+    for_each_point<D, BLOCK>(
+        N, vec,
+        [&](long c) {
+            float xp[PPT][D], yp[PPT][D];
+            load_chunk<D>(xs, c, xp);
+            load_chunk<D>(ys, c, yp);
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) one(xp[i], yp[i]);
+        },
+        [&](long n) {
+            float xp[D], yp[D];
+            load_point<D>(xs, n, xp);
+            load_point<D>(ys, n, yp);
+            one(xp, yp);
+        });
+    emit_partials<NACC>(acc, ws);
+}
+
+// ---------------------------------------------------------------------------------------
+// S1: linear-latent symmetry regulariser
+//   u = Xi_m (J_Theta(z) L z) - L (Xi_m Theta(z));  loss = sum |u|^2 over points and generators;
+//   dloss/dXi[j,k] = 2 sum ( u_j dth_k - (L^T u)_j th_k ).
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __restrict__ z, long N, bool vec,
+                                                              const float* __restrict__ xi,
+                                                              const float* __restrict__ mask,
+                                                              const float* __restrict__ Lg, int n_gen,
+                                                              double* __restrict__ ws) {
+    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NACC = 1 + D * P;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, 0, w);
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+
+    auto one = [&](const float (&zp)[D]) {
+        for (int g = 0; g < n_gen; ++g) {
+            float L[D][D];
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b < D; ++b) L[a][b] = Lg[(g * D + a) * D + b];
+            float v[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                float t = 0.0f;
+#pragma unroll
+                for (int b = 0; b < D; ++b) t = fmaf(L[a][b], zp[b], t);
+                v[a] = t;
+            }
+            float th[P], dth[P], h[D], jv[D], u[D], ltu[D];
+            Lib::eval_jvp(zp, v, th, dth);
+            apply_xi<Lib>(w, th, h);
+            apply_xi<Lib>(w, dth, jv);
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                float t = jv[a];
+#pragma unroll
+                for (int b = 0; b < D; ++b) t = fmaf(-L[a][b], h[b], t);
+                u[a] = t;
+                acc[0] = fmaf(t, t, acc[0]);
+            }
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                float t = 0.0f;
+#pragma unroll
+                for (int a = 0; a < D; ++a) t = fmaf(L[a][b], u[a], t);
+                ltu[b] = t;
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+#pragma unroll
+                for (int k = 0; k < P; ++k)
+                    acc[1 + j * P + k] += u[j] * dth[k] - ltu[j] * th[k];
+        }
+    };
+    for_each_point<D, BLOCK>(
+        N, vec,
+        [&](long c) {
+            float zp[PPT][D];
+            load_chunk<D>(z, c, zp);
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) one(zp[i]);
+        },
+        [&](long n) {
+            float zp[D];
+            load_point<D>(z, n, zp);
+            one(zp);
+        });
+    emit_partials<NACC>(acc, ws);
+}
+
+// ---------------------------------------------------------------------------------------
+// S4: reversed symmetry regulariser with precomputed (g(x), J_g(x))
+//   u = J_g(x) h(x) - h(g(x));  loss = sum_g mean(u^2);
+//   dloss/dXi[j,k] = (2/(N D)) sum ( (J_g^T u)_j th_k(x) - u_j th_k(g x) ).
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gx,
+                                                                const float* __restrict__ jgx, int n_g, long N,
+                                                                const float* __restrict__ xi,
+                                                                const float* __restrict__ mask,
+                                                                double* __restrict__ ws) {
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, 0, w);
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    for (long n = tid; n < N; n += nthreads) {
+        float xp[D], th[P], h[D];
+        load_point<D>(x, n, xp);
+        Lib::eval(xp, th);
+        apply_xi<Lib>(w, th, h);
+        for (int g = 0; g < n_g; ++g) {
+            float gp[D], J[D][D], thg[P], hg[D], u[D], jtu[D];
+            load_point<D>(gx + (long)g * N * D, n, gp);
+            const float* Jp = jgx + ((long)g * N + n) * D * D;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b < D; ++b) J[a][b] = Jp[a * D + b];
+            Lib::eval(gp, thg);
+            apply_xi<Lib>(w, thg, hg);
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                float t = -hg[a];
+#pragma unroll
+                for (int b = 0; b < D; ++b) t = fmaf(J[a][b], h[b], t);
+                u[a] = t;
+                acc[0] = fmaf(t, t, acc[0]);
+            }
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                float t = 0.0f;
+#pragma unroll
+                for (int a = 0; a < D; ++a) t = fmaf(J[a][b], u[a], t);
+                jtu[b] = t;
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+#pragma unroll
+                for (int k = 0; k < P; ++k) acc[1 + j * P + k] += jtu[j] * th[k] - u[j] * thg[k];
+        }
+    }
+    emit_partials<NACC>(acc, ws);
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+#define SYMODE_LAUNCH_CHECK() \
+    do {                      \
+        hipError_t e_ = hipGetLastError(); \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+template <class Lib>
+hipError_t launch_theta(const float* x, long n, float* out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const int g = grid_x_for(n, 1, Chunk<Lib::D>::PPT);
+    theta_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, n, vec_ok(x, n, Lib::D, 1), out);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_forward(const float* x, long n, const float* xi, const float* mask, float* out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const int g = grid_x_for(n, 1, Chunk<Lib::D>::PPT);
+    const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(out, n, Lib::D, 1);
+    forward_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, n, vec, xi, mask, out);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_odeint(const float* x, long n, const float* xi, const float* mask, int n_steps, float dt, int method,
+                         float* out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const int g = grid_x_for(n, 1, Chunk<Lib::D>::PPT);
+    const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(out, n, Lib::D, 1);
+    odeint_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, n, vec, xi, mask, n_steps, dt, method, out);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, const float* xi, const float* mask,
+                            float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
+    constexpr int NACC = 1 + Lib::D * Lib::P;
+    const bool vec = vec_ok(x, n, Lib::D, S) && vec_ok(dx, n, Lib::D, S);
+    loss_grad_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, vec, xi, mask, ws);
+    SYMODE_LAUNCH_CHECK();
+    finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv_count, 2.0f * inv_count, loss,
+                                                               grad);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_symreg_linear(const float* z, long n, const float* xi, const float* mask, const float* L, int n_gen,
+                                float* loss, float* grad, double* ws, int gx, hipStream_t st) {
+    constexpr int NACC = 1 + Lib::D * Lib::P;
+    symreg_linear_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(z, n, vec_ok(z, n, Lib::D, 1), xi, mask, L, n_gen,
+                                                                  ws);
+    SYMODE_LAUNCH_CHECK();
+    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 1.0f, 2.0f, loss, grad);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_symreg_reversed(const float* x, const float* gxp, const float* jgx, int n_g, long n, const float* xi,
+                                  const float* mask, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
+    constexpr int NACC = 1 + Lib::D * Lib::P;
+    symreg_reversed_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, gxp, jgx, n_g, n, xi, mask, ws);
+    SYMODE_LAUNCH_CHECK();
+    const float inv = 1.0f / ((float)n * (float)Lib::D);
+    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv, 2.0f * inv, loss, grad);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace symode

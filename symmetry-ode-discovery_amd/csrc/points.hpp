@@ -1,0 +1,78 @@
+// Coalesced access to (N, D) row-major fp32 trajectory arrays.
+//
+// The flattened trajectory tensor (n_ics*n_steps, D) (reference dataset.py:193-194) is read
+// as a stream of 16-byte vectors: one "chunk" per lane per step holds PPT whole points
+// (D=1: 4 points in one dwordx4, D=2: 2 points, D=3: 4 points in three dwordx4, D=4: 1).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace symode {
+
+template <int D>
+struct Chunk {
+    static constexpr int PPT = (D == 1) ? 4 : (D == 2) ? 2 : (D == 3) ? 4 : 1;   // points per chunk
+    static constexpr int NV = PPT * D / 4;                                         // dwordx4 per chunk
+    static_assert(PPT * D == NV * 4, "chunk must be a whole number of 16-byte vectors");
+};
+
+template <int D>
+__device__ __forceinline__ void load_chunk(const float* __restrict__ a, long c, float (&p)[Chunk<D>::PPT][D]) {
+    constexpr int NV = Chunk<D>::NV;
+    const float4* q = reinterpret_cast<const float4*>(a) + c * NV;
+    float f[NV * 4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 v = q[i];
+        f[4 * i + 0] = v.x;
+        f[4 * i + 1] = v.y;
+        f[4 * i + 2] = v.z;
+        f[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NV * 4; ++i) p[i / D][i % D] = f[i];
+}
+
+template <int D>
+__device__ __forceinline__ void store_chunk(float* __restrict__ a, long c, const float (&p)[Chunk<D>::PPT][D]) {
+    constexpr int NV = Chunk<D>::NV;
+    float4* q = reinterpret_cast<float4*>(a) + c * NV;
+    float f[NV * 4];
+#pragma unroll
+    for (int i = 0; i < NV * 4; ++i) f[i] = p[i / D][i % D];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+}
+
+template <int D>
+__device__ __forceinline__ void load_point(const float* __restrict__ a, long n, float (&p)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) p[i] = a[n * D + i];
+}
+
+template <int D>
+__device__ __forceinline__ void store_point(float* __restrict__ a, long n, const float (&p)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) a[n * D + i] = p[i];
+}
+
+// Visit every point of one (N, D) problem with the calling block's threads:
+//   vec == true : grid-stride over 16-byte chunks, then the < PPT leftover points;
+//   vec == false: grid-stride over single points (unaligned base or ragged row length).
+// `body(n, loader)` receives the point index and is expected to pull its operands through
+// the PointSource helpers below.
+template <int D, int BLOCK, typename ChunkBody, typename PointBody>
+__device__ __forceinline__ void for_each_point(long N, bool vec, ChunkBody chunk_body, PointBody point_body) {
+    constexpr int PPT = Chunk<D>::PPT;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
+    const long nthreads = (long)gridDim.x * BLOCK;
+    if (vec) {
+        const long nchunks = N / PPT;
+        for (long c = tid; c < nchunks; c += nthreads) chunk_body(c);
+        const long n = nchunks * PPT + tid;
+        if (n < N) point_body(n);
+    } else {
+        for (long n = tid; n < N; n += nthreads) point_body(n);
+    }
+}
+
+}  // namespace symode

@@ -1,0 +1,240 @@
+"""ctypes binding of libsymode_hip.so (C ABI: include/symode.h) on PyTorch-ROCm tensors.
+
+PyTorch is used here for device memory, streams and nothing else: every method takes CUDA
+(= HIP) fp32 tensors, hands their ``data_ptr()`` to the C ABI on torch's current stream and
+returns tensors allocated by torch.  There is NO CPU fallback: a missing library, a missing
+GPU or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+import torch
+
+FLAG_SINE = 1
+FLAG_EXP = 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsymode_hip.so")
+
+# name -> (restype, argtypes); kept in step with include/symode.h (tests check every symbol)
+_SIGNATURES = {
+    "symode_abi_version": (c_int, []),
+    "symode_error_string": (c_char_p, [c_int]),
+    "symode_lib_size": (c_int, [c_int, c_int, c_int]),
+    "symode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_long, c_long]),
+    "symode_theta": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "symode_forward": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "symode_odeint": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
+                              c_void_p, c_void_p]),
+    "symode_loss_grad": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_aug_gram": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                c_void_p]),
+    "symode_symreg_linear": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_symreg_reversed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+ABI_VERSION = 1
+
+
+class SymodeError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the HIP library and declare every entry point; raises if it is not built."""
+    if not os.path.exists(path):
+        raise SymodeError(
+            f"{path} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.symode_abi_version() != ABI_VERSION:
+        raise SymodeError(f"libsymode_hip ABI {lib.symode_abi_version()} != binding ABI {ABI_VERSION}")
+    return lib
+
+
+def library_flags(include_sine: bool, include_exp: bool) -> int:
+    return (FLAG_SINE if include_sine else 0) | (FLAG_EXP if include_exp else 0)
+
+
+class HipEngine:
+    """The product's only compute backend for the hot path."""
+
+    def __init__(self, path: str = LIB_PATH):
+        self.lib = load_library(path)
+        self._ws = {}     # (device index, stream) -> scratch tensor (grown on demand, reused)
+
+    # -- plumbing ----------------------------------------------------------------------
+    def _check(self, code: int, what: str):
+        if code != 0:
+            raise SymodeError(f"{what} failed: {self.lib.symode_error_string(code).decode()} (code {code})")
+
+    @staticmethod
+    def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise SymodeError(f"{name} must be a CUDA/HIP tensor; the hot path has no CPU fallback")
+        if t.dtype != dtype:
+            raise SymodeError(f"{name} must be {dtype}, got {t.dtype}")
+        return t.contiguous()
+
+    @staticmethod
+    def _ptr(t):
+        return None if t is None else c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _stream(t: torch.Tensor):
+        return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def lib_size(self, d: int, order: int, flags: int) -> int:
+        p = self.lib.symode_lib_size(d, order, flags)
+        if p < 0:
+            raise SymodeError(f"library d={d} order={order} flags={flags} is not compiled into libsymode_hip")
+        return p
+
+    def workspace(self, device, d, order, flags, n_problems, n) -> torch.Tensor:
+        need = self.lib.symode_workspace_bytes(d, order, flags, n_problems, n)
+        dev = torch.device(device)
+        key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)   # one scratch per (device, stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 8 < need:
+            ws = torch.empty(max(need // 8 + 1, 1024), dtype=torch.float64, device=device)
+            self._ws[key] = ws
+        return ws
+
+    # -- entry points ------------------------------------------------------------------
+    def theta(self, x, order, flags=0):
+        x = self._dev(x, "x")
+        lead, d = x.shape[:-1], x.shape[-1]
+        n = x.numel() // d if d else 0
+        p = self.lib_size(d, order, flags)
+        out = torch.empty(*lead, p, dtype=torch.float32, device=x.device)
+        self._check(self.lib.symode_theta(self._ptr(x), n, d, order, flags, self._ptr(out), self._stream(x)), "symode_theta")
+        return out
+
+    def forward(self, x, xi, mask, order, flags=0):
+        x = self._dev(x, "x")
+        d = x.shape[-1]
+        n = x.numel() // d
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        self._check_coef(xi, mask, d, order, flags)
+        out = torch.empty_like(x)
+        self._check(self.lib.symode_forward(self._ptr(x), n, d, order, flags, self._ptr(xi), self._ptr(mask),
+                                            self._ptr(out), self._stream(x)), "symode_forward")
+        return out
+
+    def odeint(self, x, xi, mask, order, flags, n_steps, dt, method="euler"):
+        x = self._dev(x, "x")
+        d = x.shape[-1]
+        n = x.numel() // d
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        self._check_coef(xi, mask, d, order, flags)
+        m = {"euler": 0, "rk4": 1}.get(method)
+        if m is None:
+            raise ValueError("Unrecognized ODEInt method.")
+        out = torch.empty_like(x)
+        self._check(self.lib.symode_odeint(self._ptr(x), n, d, order, flags, self._ptr(xi), self._ptr(mask), int(n_steps),
+                                           float(dt), m, self._ptr(out), self._stream(x)), "symode_odeint")
+        return out
+
+    def _check_coef(self, xi, mask, d, order, flags, n_problems=1):
+        p = self.lib_size(d, order, flags)
+        want = n_problems * d * p
+        if xi.numel() != want:
+            raise SymodeError(f"xi has {xi.numel()} elements, expected {n_problems}x{d}x{p}")
+        if mask is not None and mask.numel() != want:
+            raise SymodeError(f"mask has {mask.numel()} elements, expected {n_problems}x{d}x{p}")
+        return p
+
+    def loss_grad(self, x, dx, xi, mask, order, flags=0, inv_count=None, out=None):
+        """x, dx: (S, N, d) or (N, d); xi, mask: (S, d, p) or (d, p).  Returns (loss (S,), grad (S, d, p))."""
+        x, dx = self._dev(x, "x"), self._dev(dx, "dx")
+        if x.shape != dx.shape:
+            raise SymodeError(f"x {tuple(x.shape)} and dx {tuple(dx.shape)} differ")
+        batched = x.dim() == 3
+        S = x.shape[0] if batched else 1
+        n, d = x.shape[-2], x.shape[-1]
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        p = self._check_coef(xi, mask, d, order, flags, S)
+        if out is None:
+            loss = torch.empty(S, dtype=torch.float32, device=x.device)
+            grad = torch.empty(S, d, p, dtype=torch.float32, device=x.device)
+        else:
+            loss, grad = out
+        ws = self.workspace(x.device, d, order, flags, S, n)
+        inv = 1.0 / (n * d) if inv_count is None else float(inv_count)
+        self._check(self.lib.symode_loss_grad(self._ptr(x), self._ptr(dx), S, n, d, order, flags, self._ptr(xi),
+                                              self._ptr(mask), inv, self._ptr(loss), self._ptr(grad), self._ptr(ws),
+                                              ws.numel() * 8, self._stream(x)), "symode_loss_grad")
+        if not batched:
+            return loss[0], grad[0]
+        return loss, grad
+
+    def aug_gram(self, x, dx, order, flags=0):
+        """fp64 augmented Gram [Theta | dx]^T [Theta | dx]: (S, p+d, p+d) or (p+d, p+d)."""
+        x, dx = self._dev(x, "x"), self._dev(dx, "dx")
+        if x.shape != dx.shape:
+            raise SymodeError(f"x {tuple(x.shape)} and dx {tuple(dx.shape)} differ")
+        batched = x.dim() == 3
+        S = x.shape[0] if batched else 1
+        n, d = x.shape[-2], x.shape[-1]
+        p = self.lib_size(d, order, flags)
+        gram = torch.empty(S, p + d, p + d, dtype=torch.float64, device=x.device)
+        ws = self.workspace(x.device, d, order, flags, S, n)
+        self._check(self.lib.symode_aug_gram(self._ptr(x), self._ptr(dx), S, n, d, order, flags, self._ptr(gram),
+                                             self._ptr(ws), ws.numel() * 8, self._stream(x)), "symode_aug_gram")
+        return gram if batched else gram[0]
+
+    def symreg_linear(self, z, xi, mask, L, order, flags=0):
+        z = self._dev(z, "z")
+        n, d = z.shape[-2], z.shape[-1]
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        p = self._check_coef(xi, mask, d, order, flags)
+        L = self._dev(L, "L").reshape(-1, d, d)
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        grad = torch.empty(d, p, dtype=torch.float32, device=z.device)
+        ws = self.workspace(z.device, d, order, flags, 1, n)
+        self._check(self.lib.symode_symreg_linear(self._ptr(z), n, d, order, flags, self._ptr(xi), self._ptr(mask),
+                                                  self._ptr(L), L.shape[0], self._ptr(loss), self._ptr(grad),
+                                                  self._ptr(ws), ws.numel() * 8, self._stream(z)), "symode_symreg_linear")
+        return loss[0], grad
+
+    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0):
+        x, gx, jgx = self._dev(x, "x"), self._dev(gx, "gx"), self._dev(jgx, "jgx")
+        n, d = x.shape[-2], x.shape[-1]
+        n_g = gx.shape[0]
+        if gx.shape != (n_g, n, d) or jgx.shape != (n_g, n, d, d):
+            raise SymodeError(f"gx {tuple(gx.shape)} / jgx {tuple(jgx.shape)} do not match x {tuple(x.shape)}")
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        p = self._check_coef(xi, mask, d, order, flags)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        grad = torch.empty(d, p, dtype=torch.float32, device=x.device)
+        ws = self.workspace(x.device, d, order, flags, 1, n)
+        self._check(self.lib.symode_symreg_reversed(self._ptr(x), self._ptr(gx), self._ptr(jgx), n_g, n, d, order, flags,
+                                                    self._ptr(xi), self._ptr(mask), self._ptr(loss), self._ptr(grad),
+                                                    self._ptr(ws), ws.numel() * 8, self._stream(x)),
+                    "symode_symreg_reversed")
+        return loss[0], grad
+
+
+_ENGINE = None
+
+
+def get_engine() -> HipEngine:
+    """Process-wide engine; raises SymodeError if libsymode_hip.so is not built."""
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = HipEngine()
+    return _ENGINE

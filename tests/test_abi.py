@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+that include/symode.h declares; argument validation returns error codes without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import symode_amd
+from symode_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "symode.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(engine.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return engine.load_library()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(symode_[a-z_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/symode.h but not exported"
+        assert n in engine._SIGNATURES, f"{n} has no ctypes signature in engine.py"
+    assert sorted(engine._SIGNATURES) == names
+
+
+def test_abi_version_and_error_strings(lib):
+    assert lib.symode_abi_version() == engine.ABI_VERSION
+    assert lib.symode_error_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert len(lib.symode_error_string(code)) > 3
+
+
+def test_lib_size_matches_reference_term_count(lib):
+    # reference sindy.py:179-189 (orders <= 3), C(d+n-1, n) beyond
+    from math import comb
+    for d in (1, 2, 3, 4):
+        for order in (1, 2, 3, 4, 5):
+            for fl in (0, 1, 2, 3):
+                p = 1 + sum(comb(d + n - 1, n) for n in range(1, order + 1)) + d * bin(fl).count("1")
+                got = lib.symode_lib_size(d, order, fl)
+                supported = (d <= 2) or (d == 3 and order <= 4) or (d == 4 and order <= 3)
+                assert got == (p if supported else -1), (d, order, fl)
+    assert lib.symode_lib_size(2, 3, 0) == 10 and lib.symode_lib_size(2, 2, 2) == 8 and lib.symode_lib_size(2, 5, 0) == 21
+    assert lib.symode_lib_size(5, 2, 0) == -1 and lib.symode_lib_size(2, 6, 0) == -1 and lib.symode_lib_size(2, 2, 4) == -1
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    null = ctypes.c_void_p(None)
+    assert lib.symode_theta(null, -1, 2, 3, 0, null, null) == -3          # bad size
+    assert lib.symode_theta(null, 0, 2, 3, 0, null, null) == 0            # empty input: nothing to do
+    assert lib.symode_theta(null, 8, 2, 3, 0, null, null) == -2           # null pointers
+    assert lib.symode_theta(null, 8, 7, 3, 0, null, null) == -1           # unsupported library
+    assert lib.symode_loss_grad(null, null, 1, 8, 2, 3, 0, null, null, 1.0, null, null, null, 0, null) == -2
+    assert lib.symode_loss_grad(null, null, 0, 8, 2, 3, 0, null, null, 1.0, null, null, null, 0, null) == -3
+    assert lib.symode_workspace_bytes(2, 3, 0, 1, 125000) > 0
+    assert lib.symode_workspace_bytes(9, 3, 0, 1, 125000) == 0
+
+
+def test_engine_refuses_cpu_tensors():
+    import torch
+    eng = symode_amd.get_engine()
+    with pytest.raises(symode_amd.SymodeError):
+        eng.theta(torch.zeros(4, 2), 3)
+    with pytest.raises(symode_amd.SymodeError):
+        eng.loss_grad(torch.zeros(4, 2), torch.zeros(4, 2), torch.zeros(2, 10), None, 3)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(symode_amd.SymodeError):
+        engine.load_library(str(tmp_path / "nope.so"))

@@ -1,0 +1,254 @@
+"""GPU parity tests proper: HIP kernels (through the C ABI) vs the CPU oracle and golden vectors.
+
+Tolerances (north_star: coefficients within rtol 1e-5 fp32, masks bit-exact):
+  * polynomial library columns: bit-exact (same left-to-right fp32 products as the reference);
+  * sin / exp columns: 2 ulp-level relative tolerance (device libm vs torch CPU SLEEF);
+  * reductions (loss, gradient): rtol 1e-5 relative to the gradient's scale;
+  * fp64 Gram: rtol 1e-12 against an fp64 host product of the same fp32 library.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sindy_oracle as O
+from tests.helpers import TinyAE, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import symode_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return symode_amd.get_engine()
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32).cuda()
+
+
+def flags_of(sine, exp):
+    return (1 if sine else 0) | (2 if exp else 0)
+
+
+def assert_close_scaled(got, want, rtol=1e-5, what=""):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert err <= rtol, f"{what}: max scaled error {err:.3e} > {rtol}"
+
+
+# ----------------------------------------------------------------------------------- theta
+def test_theta_golden_bit_exact(eng, golden):
+    g = golden("f1_theta")
+    for key in g["cases"]:
+        d, order, sine, exp = (int(key[1]), int(key[4]), key[7] == "1", key[10] == "1")
+        x = dev(g[f"x_d{d}"])
+        got = eng.theta(x, order, flags_of(sine, exp)).cpu().numpy()
+        want = g["theta_" + key]
+        npoly = O.term_count(d, order)
+        assert got.shape == want.shape
+        assert np.array_equal(got[:, :npoly], want[:, :npoly]), key      # bit-exact monomials
+        if want.shape[1] > npoly:
+            assert np.allclose(got[:, npoly:], want[:, npoly:], rtol=3e-7, atol=1e-7), key
+    got = eng.theta(dev(g["probe_x"]), 3).cpu().numpy()
+    assert got[0].tolist() == [1, 2, 3, 4, 6, 9, 8, 12, 18, 27]
+
+
+@pytest.mark.parametrize("d,order", [(1, 5), (2, 4), (2, 5), (3, 4), (4, 3)])
+def test_theta_high_order_vs_oracle(eng, d, order):
+    """Orders 4-5 extend the reference ordering (parity unpinned by the reference itself)."""
+    torch.manual_seed(d * 10 + order)
+    for n in (1, 2, 3, 5, 64, 257, 1000):
+        x = torch.randn(n, d)
+        got = eng.theta(x.cuda(), order).cpu()
+        assert torch.equal(got, O.theta(x, order)), (d, order, n)
+
+
+def test_theta_leading_dims_and_empty(eng):
+    x = torch.randn(7, 5, 2)
+    assert torch.equal(eng.theta(x.cuda(), 3).cpu(), O.theta(x, 3))
+    assert eng.theta(torch.empty(0, 2).cuda(), 3).shape == (0, 10)
+
+
+# --------------------------------------------------------------------------------- forward
+@pytest.mark.parametrize("tag", ["o3", "o2e", "d3o2s"])
+def test_forward_loss_grad_golden(eng, golden, tag):
+    g = golden("f2_fwd_loss_grad")
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    fl = flags_of(sine, exp)
+    x, dx, Xi, mask = (dev(g[f"{tag}_{k}"]) for k in ("x", "dx", "Xi", "mask"))
+    pred = eng.forward(x, Xi, mask, order, fl).cpu().numpy()
+    assert_close_scaled(pred, g[f"{tag}_pred"], 2e-6, "forward")
+    loss, grad = eng.loss_grad(x, dx, Xi, mask, order, fl)
+    assert np.isclose(loss.item(), float(g[f"{tag}_loss"]), rtol=1e-5)
+    assert_close_scaled(grad.cpu().numpy(), g[f"{tag}_grad_mse"], 1e-5, "grad")
+    # masked entries get exactly zero gradient, as autograd through Xi*mask gives
+    assert np.all(grad.cpu().numpy()[g[f"{tag}_mask"] == 0] == 0.0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 65, 255, 1023, 4097, 125000])
+@pytest.mark.parametrize("d,order,fl", [(2, 3, 0), (2, 5, 0), (1, 3, 1), (3, 2, 2), (4, 2, 0)])
+def test_loss_grad_ragged_sizes_vs_oracle(eng, n, d, order, fl):
+    torch.manual_seed(n + 7 * d + order)
+    x, dx = torch.randn(n, d) * 0.8, torch.randn(n, d)
+    p = O.term_count(d, order, bool(fl & 1), bool(fl & 2))
+    Xi = torch.randn(d, p) * 0.5
+    mask = (torch.rand(d, p) > 0.25).float()
+    wl, wg = O.mse_loss_and_grad(x.double(), dx.double(), Xi.double(), mask.double(), order, bool(fl & 1), bool(fl & 2))
+    loss, grad = eng.loss_grad(x.cuda(), dx.cuda(), Xi.cuda(), mask.cuda(), order, fl)
+    assert np.isclose(loss.item(), wl.item(), rtol=2e-5), (n, d, order)
+    assert_close_scaled(grad.cpu().numpy(), wg.numpy(), 2e-5, f"grad n={n}")
+
+
+def test_loss_grad_unaligned_base_pointer(eng):
+    """x[1:] starts 8 bytes into the allocation: the kernel must take its scalar-load path."""
+    torch.manual_seed(3)
+    x, dx = torch.randn(1001, 2), torch.randn(1001, 2)
+    Xi = torch.randn(2, 10)
+    xs, dxs = x.cuda()[1:], dx.cuda()[1:]
+    assert xs.data_ptr() % 16 != 0
+    loss, grad = eng.loss_grad(xs, dxs, Xi.cuda(), None, 3)
+    wl, wg = O.mse_loss_and_grad(x[1:].double(), dx[1:].double(), Xi.double(), torch.ones(2, 10).double(), 3)
+    assert np.isclose(loss.item(), wl.item(), rtol=2e-5)
+    assert_close_scaled(grad.cpu().numpy(), wg.numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("S,n", [(3, 1000), (5, 999), (64, 2500), (300, 50)])
+def test_loss_grad_batched_problems(eng, S, n):
+    """Independent (trajectory, seed) problems in one launch, own Xi / mask each (odd n: ragged rows)."""
+    torch.manual_seed(S)
+    d, order, p = 2, 3, 10
+    x, dx = torch.randn(S, n, d) * 0.7, torch.randn(S, n, d)
+    Xi, mask = torch.randn(S, d, p), (torch.rand(S, d, p) > 0.3).float()
+    loss, grad = eng.loss_grad(x.cuda(), dx.cuda(), Xi.cuda(), mask.cuda(), order)
+    assert loss.shape == (S,) and grad.shape == (S, d, p)
+    for s in range(0, S, max(1, S // 7)):
+        wl, wg = O.mse_loss_and_grad(x[s].double(), dx[s].double(), Xi[s].double(), mask[s].double(), order)
+        assert np.isclose(loss[s].item(), wl.item(), rtol=2e-5)
+        assert_close_scaled(grad[s].cpu().numpy(), wg.numpy(), 2e-5)
+
+
+def test_loss_grad_is_deterministic(eng):
+    torch.manual_seed(0)
+    x, dx, Xi = torch.randn(125000, 2).cuda(), torch.randn(125000, 2).cuda(), torch.randn(2, 21).cuda()
+    a = eng.loss_grad(x, dx, Xi, None, 5)
+    a = (a[0].clone(), a[1].clone())
+    for _ in range(3):
+        b = eng.loss_grad(x, dx, Xi, None, 5)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_loss_grad_inv_count_sharding_identity(eng):
+    """Two half-shards with inv_count = 1/(N_global d) add up to the full-batch result."""
+    torch.manual_seed(1)
+    x, dx, Xi = torch.randn(5000, 2).cuda(), torch.randn(5000, 2).cuda(), torch.randn(2, 10).cuda()
+    full = eng.loss_grad(x, dx, Xi, None, 3)
+    full = (full[0].clone(), full[1].clone())
+    inv = 1.0 / (5000 * 2)
+    a = eng.loss_grad(x[:2000], dx[:2000], Xi, None, 3, inv_count=inv)
+    a = (a[0].clone(), a[1].clone())
+    b = eng.loss_grad(x[2000:], dx[2000:], Xi, None, 3, inv_count=inv)
+    assert torch.allclose(a[0] + b[0], full[0], rtol=1e-5)
+    assert torch.allclose(a[1] + b[1], full[1], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------- odeint
+@pytest.mark.parametrize("tag", ["relu_sim2", "tanh_learn"])
+def test_odeint_golden(eng, golden, tag):
+    g = golden("f6_symreg")
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    fl = flags_of(sine, exp)
+    x, Xi, mask = dev(g[f"{tag}_x"]), dev(g[f"{tag}_Xi"]), dev(g[f"{tag}_mask"])
+    K, dt = int(g[f"{tag}_K"]), float(g[f"{tag}_dt"])
+    got = eng.odeint(x, Xi, mask, order, fl, K, dt, "euler").cpu().numpy()
+    assert np.allclose(got, g[f"{tag}_euler"], rtol=1e-5, atol=1e-6)
+    got = eng.odeint(x, Xi, mask, order, fl, K, dt, "rk4").cpu().numpy()
+    assert np.allclose(got, g[f"{tag}_rk4"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(eng.odeint(x, Xi, mask, order, fl, 0, dt), x)
+
+
+# ------------------------------------------------------------------------------------ gram
+@pytest.mark.parametrize("d,order,fl", [(2, 2, 0), (2, 3, 0), (2, 5, 0), (2, 2, 2), (3, 3, 0), (1, 4, 3), (4, 3, 0), (3, 4, 1)])
+@pytest.mark.parametrize("n", [1, 63, 256, 257, 5000])
+def test_aug_gram_vs_fp64_host(eng, d, order, fl, n):
+    torch.manual_seed(n + order)
+    x, dx = torch.randn(n, d) * 0.9, torch.randn(n, d)
+    A = torch.cat([O.theta(x, order, bool(fl & 1), bool(fl & 2)), dx], dim=1)
+    got = eng.aug_gram(x.cuda(), dx.cuda(), order, fl).cpu()
+    npoly = O.term_count(d, order)
+    # polynomial + dx block: the fp32 features are bit-identical, so only fp64 summation order differs
+    idx = list(range(npoly)) + list(range(A.shape[1] - d, A.shape[1]))
+    want = A.double().T @ A.double()
+    sub_g, sub_w = got[idx][:, idx], want[idx][:, idx]
+    assert torch.allclose(sub_g, sub_w, rtol=1e-12, atol=1e-12 * sub_w.abs().max().item())
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6 * want.abs().max().item())     # sin/exp: libm ulps
+    assert torch.equal(got, got.T)
+
+
+def test_aug_gram_batched_and_asymmetric_tiles(eng):
+    """Off-diagonal 16x16 tiles (p+d = 23 > 16) catch a transposed MFMA C/D mapping."""
+    torch.manual_seed(5)
+    S, n, d, order = 6, 777, 2, 5
+    x, dx = torch.rand(S, n, d) + 0.5, torch.randn(S, n, d)
+    got = eng.aug_gram(x.cuda(), dx.cuda(), order).cpu()
+    for s in range(S):
+        A = torch.cat([O.theta(x[s], order), dx[s]], dim=1).double()
+        assert torch.allclose(got[s], A.T @ A, rtol=1e-12, atol=0)
+
+
+def test_gram_reproduces_loss_and_grad_at_full_size(eng):
+    """Size-independent property at the BASELINE shape (50 x 2500 x 2, order 5):
+    loss and gradient are quadratic forms of the augmented Gram matrix."""
+    torch.manual_seed(11)
+    N, d, order, p = 125000, 2, 5, 21
+    x, dx = (torch.randn(N, d) * 0.6).cuda(), torch.randn(N, d).cuda()
+    Xi, mask = torch.randn(d, p).cuda() * 0.3, (torch.rand(d, p) > 0.2).float().cuda()
+    loss, grad = eng.loss_grad(x, dx, Xi, mask, order)
+    G = eng.aug_gram(x, dx, order)
+    W = (Xi * mask).double()
+    Gtt, Gty, Gyy = G[:p, :p], G[:p, p:], G[p:, p:]
+    want_loss = (torch.trace(W @ Gtt @ W.T) - 2 * torch.trace(W @ Gty) + torch.trace(Gyy)) / (N * d)
+    want_grad = 2.0 / (N * d) * (W @ Gtt - Gty.T) * mask.double()
+    assert np.isclose(loss.item(), want_loss.item(), rtol=1e-5)
+    assert_close_scaled(grad.cpu().numpy(), want_grad.cpu().numpy(), 1e-5)
+
+
+# --------------------------------------------------------------------------------- sym-reg
+@pytest.mark.parametrize("tag,act", [("relu_sim2", "ReLU"), ("tanh_learn", "Tanh")])
+def test_symreg_linear_and_reversed_golden(eng, golden, tag, act):
+    g = golden("f6_symreg")
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    fl = flags_of(sine, exp)
+    x, Xi, mask = dev(g[f"{tag}_x"]), dev(g[f"{tag}_Xi"]), dev(g[f"{tag}_mask"])
+    # S1
+    loss, grad = eng.symreg_linear(x, Xi, mask, dev(g[f"{tag}_s1_L"]), order, fl)
+    assert np.isclose(loss.item(), float(g[f"{tag}_s1_loss"]), rtol=2e-5)
+    assert_close_scaled(grad.cpu().numpy(), g[f"{tag}_s1_grad"], 5e-5, "s1 grad")
+    # S4 with (g(x), J_g(x)) precomputed by the oracle from the frozen tiny autoencoder
+    ae = TinyAE(g, tag, act)
+    gel = [t(e) for e in g[f"{tag}_gelems_r"]]
+    gx, Jgx = O.precompute_group_jacobians(t(g[f"{tag}_x"]), ae.encode, ae.decode, ae.z_mean, gel)
+    loss, grad = eng.symreg_reversed(x, torch.stack(gx).cuda(), torch.stack(Jgx).cuda(), Xi, mask, order, fl)
+    assert np.isclose(loss.item(), float(g[f"{tag}_s4_loss"]), rtol=1e-3)
+    assert_close_scaled(grad.cpu().numpy(), g[f"{tag}_s4_grad"], 5e-3, "s4 grad")
+    # and tightly against the oracle's own precomputed formulation (same inputs)
+    reg = O.OracleRegressor(d, order, bool(sine), bool(exp), Xi0=t(g[f"{tag}_Xi"]))
+    reg.mask = t(g[f"{tag}_mask"])
+    ol = O.symreg_reversed_precomputed(t(g[f"{tag}_x"]), gx, Jgx, reg)
+    ol.backward()
+    assert np.isclose(loss.item(), ol.item(), rtol=2e-5)
+    assert_close_scaled(grad.cpu().numpy(), reg.Xi.grad.numpy(), 5e-5, "s4 grad vs oracle")
+
+
+# ------------------------------------------------------------------------- error behaviour
+def test_no_cpu_fallback_and_argument_errors(eng):
+    import symode_amd
+    with pytest.raises(symode_amd.SymodeError):
+        eng.theta(torch.randn(4, 2), 3)                      # CPU tensor: refuse, never fall back
+    with pytest.raises(symode_amd.SymodeError):
+        eng.theta(torch.randn(4, 5).cuda(), 3)               # d = 5 not compiled in
+    with pytest.raises(symode_amd.SymodeError):
+        eng.loss_grad(torch.randn(4, 2).cuda(), torch.randn(4, 2).cuda(), torch.randn(2, 9).cuda(), None, 3)
+    with pytest.raises(symode_amd.SymodeError):
+        eng.theta(torch.randn(4, 2).double().cuda(), 3)
