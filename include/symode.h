@@ -97,6 +97,20 @@ int symode_symreg_reversed(const float* x, const float* gx, const float* jgx, in
                            int flags, const float* xi, const float* mask, float* loss_out, float* grad_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Reverse mode of symode_forward, given g = dL/d(out) (n, d):
+ *   grad_x (n, d) = J_Theta(x)^T (xi*mask)^T g   (skipped when grad_x is NULL),
+ *   grad_xi (d, p) = (g^T Theta(x)) * mask.
+ * replaces: autograd's backward through sindy.py:79-82 (cat-of-products + matmul). */
+int symode_vjp(const float* x, const float* g, long n, int d, int order, int flags, const float* xi, const float* mask,
+               float* grad_x, float* grad_xi, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Forward mode: out (n, d) = Theta(x)(xi*mask)^T (skipped when out is NULL) and
+ *   jv (n, d) = (J_Theta(x) v)(xi*mask)^T  for tangents v (n, d).
+ * replaces: torch.autograd.functional.jvp(regressor, x, v)[1], the double-backward trick of
+ * model_utils.py:56, 166 and train.py:505. */
+int symode_forward_jvp(const float* x, const float* v, long n, int d, int order, int flags, const float* xi,
+                       const float* mask, float* out, float* jv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,10 +6,12 @@ root-level shim ``symode_amd.py`` is on the path, simply ``import symode_amd``.
 """
 import sys as _sys
 
-from . import engine  # noqa: F401
+from . import constraint, engine, library, lstsq, sindy  # noqa: F401
 from .engine import FLAG_EXP, FLAG_SINE, HipEngine, SymodeError, get_engine, library_flags  # noqa: F401
 
-__all__ = ["engine", "HipEngine", "SymodeError", "get_engine", "library_flags", "FLAG_SINE", "FLAG_EXP"]
+from .sindy import SINDyRegression, solve_SINDy, solve_SINDy_one_step  # noqa: F401
+
+__all__ = ["engine", "SINDyRegression", "solve_SINDy", "solve_SINDy_one_step", "HipEngine", "SymodeError", "get_engine", "library_flags", "FLAG_SINE", "FLAG_EXP"]
 
 # make the package reachable under an importable alias
 _ALIAS = "symode_amd"

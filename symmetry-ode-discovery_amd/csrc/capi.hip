@@ -157,4 +157,29 @@ int symode_symreg_reversed(const float* x, const float* gx_, const float* jgx, i
                                      (hipStream_t)stream);
 }
 
+int symode_vjp(const float* x, const float* g, long n, int d, int order, int flags, const float* xi, const float* mask,
+               float* grad_x, float* grad_xi, void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 1) return SYMODE_E_BADSIZE;
+    if (!x || !g || !xi || !grad_xi) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(g, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(grad_x, 4) ||
+        misaligned(grad_xi, 4))
+        return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(1, n);
+    const int gx = grid_x_for(n, 1, 1);
+    return (int)ops->vjp(x, g, n, xi, mask, grad_x, grad_xi, (double*)workspace, gx, (hipStream_t)stream);
+}
+
+int symode_forward_jvp(const float* x, const float* v, long n, int d, int order, int flags, const float* xi,
+                       const float* mask, float* out, float* jv, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 0) return SYMODE_E_BADSIZE;
+    if (n == 0) return SYMODE_OK;
+    if (!x || !v || !xi || !jv) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(v, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(out, 4) ||
+        misaligned(jv, 4))
+        return SYMODE_E_ALIGN;
+    return (int)ops->forward_jvp(x, v, n, xi, mask, out, jv, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -27,6 +27,10 @@ struct LibOps {
                                   const float* mask, float* loss, float* grad, double* ws, int gx, hipStream_t st);
     hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, double* gram, double* ws, int gx,
                            hipStream_t st);
+    hipError_t (*vjp)(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
+                      float* grad_xi, double* ws, int gx, hipStream_t st);
+    hipError_t (*forward_jvp)(const float* x, const float* v, long n, const float* xi, const float* mask, float* out,
+                              float* jv, hipStream_t st);
 };
 
 // ---------------------------------------------------------------------------------------
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
         v = wave_sum(v);
         if (lane == 0) {
             if (k == 0) {
-                loss[s] = (float)(v * (double)loss_scale);
+                if (loss != nullptr) loss[s] = (float)(v * (double)loss_scale);
             } else {
                 const long i = s * (nacc - 1) + (k - 1);
                 const float m = mask ? mask[i] : 1.0f;
@@ -418,6 +422,69 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------
+// vjp of forward: given g = dL/d(out) (N, D)
+//   grad_x[n] = J_Theta(x_n)^T (Xi_m^T g_n)           (optional)
+//   grad_xi   = (sum_n g_n Theta(x_n)^T) * mask        (through the partial-sum epilogue)
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x, const float* __restrict__ g, long N,
+                                                    const float* __restrict__ xi, const float* __restrict__ mask,
+                                                    float* __restrict__ grad_x, double* __restrict__ ws) {
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, 0, w);
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    for (long n = tid; n < N; n += nthreads) {
+        float xp[D], gp[D], th[P];
+        load_point<D>(x, n, xp);
+        load_point<D>(g, n, gp);
+        Lib::eval(xp, th);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(gp[j], th[k], acc[1 + j * P + k]);
+        if (grad_x != nullptr) {
+            float bar[P], bx[D];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                float t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) t = fmaf(gp[j], w[j * P + k], t);
+                bar[k] = t;
+            }
+            Lib::vjp(xp, th, bar, bx);
+            store_point<D>(grad_x, n, bx);
+        }
+    }
+    emit_partials<NACC>(acc, ws);
+}
+
+// out = Theta(x) Xi_m^T and jv = (J_Theta(x) v) Xi_m^T in one pass (forward-mode tangent).
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void forward_jvp_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                            long N, const float* __restrict__ xi,
+                                                            const float* __restrict__ mask, float* __restrict__ out,
+                                                            float* __restrict__ jv) {
+    constexpr int D = Lib::D, P = Lib::P;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, 0, w);
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    for (long n = tid; n < N; n += nthreads) {
+        float xp[D], vp[D], th[P], dth[P], h[D], t[D];
+        load_point<D>(x, n, xp);
+        load_point<D>(v, n, vp);
+        Lib::eval_jvp(xp, vp, th, dth);
+        apply_xi<Lib>(w, th, h);
+        apply_xi<Lib>(w, dth, t);
+        if (out != nullptr) store_point<D>(out, n, h);
+        store_point<D>(jv, n, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 #define SYMODE_LAUNCH_CHECK() \
@@ -489,6 +556,27 @@ hipError_t launch_symreg_reversed(const float* x, const float* gxp, const float*
     SYMODE_LAUNCH_CHECK();
     const float inv = 1.0f / ((float)n * (float)Lib::D);
     finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv, 2.0f * inv, loss, grad);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_vjp(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
+                      float* grad_xi, double* ws, int gx, hipStream_t st) {
+    constexpr int NACC = 1 + Lib::D * Lib::P;
+    vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, xi, mask, grad_x, ws);
+    SYMODE_LAUNCH_CHECK();
+    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_forward_jvp(const float* x, const float* v, long n, const float* xi, const float* mask, float* out,
+                              float* jv, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const int g = grid_x_for(n, 1, 1);
+    forward_jvp_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, v, n, xi, mask, out, jv);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -113,6 +113,28 @@ struct Library {
             }
         }
     }
+
+    // Reverse mode through the same recurrence: given bar_th = dL/dTheta (consumed), return
+    // bar_x = J_Theta(x)^T bar_th.  th must hold Theta(x).
+    static __device__ __forceinline__ void vjp(const float (&x)[D], const float (&th)[P], float (&bar)[P],
+                                               float (&bx)[D]) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) bx[i] = 0.0f;
+#pragma unroll
+        for (int t = NP - 1; t >= 1; --t) {
+            const int q = tab.parent[t], a = tab.var[t];
+            bx[a] = fmaf(bar[t], th[q], bx[a]);
+            if (q != 0) bar[q] = fmaf(bar[t], x[a], bar[q]);
+        }
+        if constexpr (SINE) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) bx[i] = fmaf(bar[SIN0 + i], cosf(x[i]), bx[i]);
+        }
+        if constexpr (EXP) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) bx[i] = fmaf(bar[EXP0 + i], th[EXP0 + i], bx[i]);
+        }
+    }
 };
 
 }  // namespace symode

@@ -37,6 +37,10 @@ _SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_symreg_reversed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_vjp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_size_t, c_void_p]),
+    "symode_forward_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
 }
 
 ABI_VERSION = 1
@@ -227,6 +231,37 @@ class HipEngine:
                                                     self._ptr(ws), ws.numel() * 8, self._stream(x)),
                     "symode_symreg_reversed")
         return loss[0], grad
+
+
+    def vjp(self, x, g, xi, mask, order, flags=0, need_grad_x=True):
+        """Reverse mode of forward: returns (grad_x (N, d) or None, grad_xi (d, p))."""
+        x, g = self._dev(x, "x"), self._dev(g, "g")
+        n, d = x.shape[-2], x.shape[-1]
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        p = self._check_coef(xi, mask, d, order, flags)
+        gx = torch.empty_like(x) if need_grad_x else None
+        gxi = torch.empty(d, p, dtype=torch.float32, device=x.device)
+        ws = self.workspace(x.device, d, order, flags, 1, n)
+        self._check(self.lib.symode_vjp(self._ptr(x), self._ptr(g), n, d, order, flags, self._ptr(xi), self._ptr(mask),
+                                        self._ptr(gx), self._ptr(gxi), self._ptr(ws), ws.numel() * 8, self._stream(x)),
+                    "symode_vjp")
+        return gx, gxi
+
+    def forward_jvp(self, x, v, xi, mask, order, flags=0, need_out=True):
+        """Forward mode: (out, J.v) for tangents v of x's shape."""
+        x, v = self._dev(x, "x"), self._dev(v, "v")
+        d = x.shape[-1]
+        n = x.numel() // d
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        self._check_coef(xi, mask, d, order, flags)
+        out = torch.empty_like(x) if need_out else None
+        jv = torch.empty_like(x)
+        self._check(self.lib.symode_forward_jvp(self._ptr(x), self._ptr(v), n, d, order, flags, self._ptr(xi),
+                                                self._ptr(mask), self._ptr(out), self._ptr(jv), self._stream(x)),
+                    "symode_forward_jvp")
+        return out, jv
 
 
 _ENGINE = None

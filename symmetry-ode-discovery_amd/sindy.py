@@ -1,0 +1,269 @@
+"""SINDy operator layer on the HIP engine -- same surface as the reference's ``sindy.py``.
+
+``SINDyRegression`` keeps the reference's constructor, parameter names (``Xi`` or
+``beta`` + ``const`` in the state_dict), plain-tensor attributes (``mask``, ``Q``) and methods
+(sindy.py:33-247); ``solve_SINDy_one_step`` / ``solve_SINDy`` keep their signatures and
+in-place update semantics (sindy.py:250-324).  What changes is how the numbers are made:
+
+  * Theta is never materialised on the training path: ``forward`` is one fused kernel,
+    ``mse_loss`` is the fused Theta + residual + loss + gradient kernel (symode_loss_grad);
+  * the sequential-threshold least-squares step reads the data ONCE into the fp64 augmented
+    Gram matrix (symode_aug_gram, MFMA) and solves every masked / constrained variant of the
+    reference's block-diagonal system on the host from that (p+d)^2 matrix (lstsq.py), instead
+    of building a dense (d(N+p)) x (dp) matrix per pass (sindy.py:270-273).
+
+There is no CPU fallback: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import library
+from .constraint import constraint_M, constraint_Q
+from .engine import get_engine, library_flags
+from .lstsq import lstsq_normal
+
+
+class _Forward(torch.autograd.Function):
+    """dx_hat = Theta(x) (Xi*mask)^T, differentiable once w.r.t. x and Xi (HIP forward + vjp)."""
+
+    @staticmethod
+    def forward(ctx, x, xi, mask, reg):
+        eng = reg.engine
+        ctx.reg = reg
+        ctx.save_for_backward(x, xi, mask)
+        return eng.forward(x.detach(), xi.detach(), mask, reg.poly_order, reg.flags)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xi, mask = ctx.saved_tensors
+        reg = ctx.reg
+        gx, gxi = reg.engine.vjp(x.detach(), g.contiguous(), xi.detach(), mask, reg.poly_order, reg.flags,
+                                 need_grad_x=ctx.needs_input_grad[0])
+        return gx, (gxi if ctx.needs_input_grad[1] else None), None, None
+
+
+class _FusedMSE(torch.autograd.Function):
+    """mean((Theta(x)(Xi*mask)^T - dx)^2) with its Xi-gradient from the same single pass."""
+
+    @staticmethod
+    def forward(ctx, xi, mask, x, dx, reg, inv_count):
+        loss, grad = reg.engine.loss_grad(x, dx, xi.detach(), mask, reg.poly_order, reg.flags, inv_count=inv_count)
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g * grad, None, None, None, None, None
+
+
+class SINDyRegression(nn.Module):
+    """
+    Arguments (reference sindy.py:33-42):
+        latent_dim: dimension of the state
+        poly_order: highest polynomial order (reference: max 3; here up to 5)
+        include_sine / include_exp: append sin / exp columns (forced off under the constraint)
+        L_list: list of Lie-algebra generators (d, d) -> equivariance constraint
+        kwargs: threshold, device, constrain_constant (required with L_list), lstsq_driver
+    """
+
+    def __init__(self, latent_dim, poly_order, include_sine, include_exp, L_list=[], **kwargs):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.poly_order = poly_order
+        self.constraint = (len(L_list) != 0)
+        self.include_sine = include_sine and not self.constraint        # sindy.py:47
+        self.include_exp = include_exp and not self.constraint          # sindy.py:48
+        self.L_list = L_list
+        self.threshold = kwargs["threshold"]
+        self.lstsq_driver = kwargs.get("lstsq_driver", "gelsy")
+        device = kwargs["device"]
+        self.engine = kwargs.get("engine") or get_engine()
+        self.flags = library_flags(self.include_sine, self.include_exp)
+        n_terms = self.engine.lib_size(latent_dim, poly_order, self.flags)   # raises if not compiled in
+        assert n_terms == library.term_count(latent_dim, poly_order, self.include_sine, self.include_exp)
+
+        if self.constraint:
+            print('Computing equivariance constraint...')
+            self.Q = self.get_Q().to(device)
+            self.beta = nn.Parameter(torch.randn((self.Q.shape[1]), device=device))
+            self.const = nn.Parameter(torch.randn((latent_dim, 1), device=device))
+            self.allow_constant = not kwargs['constrain_constant']
+            self.Xi = self.get_Xi()
+        else:
+            self.Xi = nn.Parameter(torch.randn(self.latent_dim, n_terms, device=device))
+        self.mask = torch.ones_like(self.Xi, device=device)
+        self._gram_cache = None
+
+    # ------------------------------------------------------------------ evaluation
+    def _coef(self):
+        self.Xi = self.get_Xi() if self.constraint else self.Xi
+        return self.Xi
+
+    def forward(self, x):
+        """Theta(x) @ (Xi * mask)^T                                      (sindy.py:79-82)"""
+        xi = self._coef()
+        lead = x.shape[:-1]
+        out = _Forward.apply(x.reshape(-1, self.latent_dim), xi, self.mask, self)
+        return out.reshape(*lead, self.latent_dim)
+
+    def mse_loss(self, x, dx, inv_count=None):
+        """Fused replacement for ``MSELoss()(regressor(x), dx)`` (train.py:663-664)."""
+        xi = self._coef()
+        return _FusedMSE.apply(xi, self.mask, x.reshape(-1, self.latent_dim), dx.reshape(-1, self.latent_dim), self,
+                               inv_count)
+
+    def eval_Theta_at(self, x):
+        """Function library without coefficients                          (sindy.py:201-203)"""
+        return self.engine.theta(x, self.poly_order, self.flags)
+
+    def jvp(self, x, v):
+        """J_regressor(x) . v  =  (J_Theta(x) v) (Xi*mask)^T -- analytic, no double backward."""
+        xi = self._coef()
+        return self.engine.forward_jvp(x, v, xi.detach(), self.mask, self.poly_order, self.flags)[1]
+
+    # ------------------------------------------------------------------ constraint
+    def get_M_list(self):
+        return [constraint_M(L, self.latent_dim, self.poly_order) for L in self.L_list]
+
+    def get_Q(self):
+        Q, self.use_kron_product = constraint_Q(self.L_list, self.latent_dim, self.poly_order)
+        return Q
+
+    def update_Q(self, new_Li):                                           # sindy.py:117-120
+        self.L_list = new_Li
+        self.Q = self.get_Q().to(self.Xi.device)
+        self.beta = nn.Parameter(torch.randn((self.Q.shape[1]), device=self.Xi.device))
+        self._gram_cache = None
+
+    def get_Xi(self):                                                     # sindy.py:169-176
+        if not self.constraint:
+            return self.Xi
+        if self.use_kron_product:
+            Xi = (self.Q @ self.beta).view(self.latent_dim, -1)
+        else:
+            Xi = (self.Q @ self.beta).view(-1, self.latent_dim).transpose(0, 1)
+        if self.allow_constant:
+            Xi = Xi + torch.cat([self.const, torch.zeros((Xi.shape[0], Xi.shape[1] - 1), device=Xi.device)], dim=1)
+        return Xi
+
+    def get_term_num(self):                                               # sindy.py:179-189
+        return library.term_count(self.latent_dim, self.poly_order, self.include_sine, self.include_exp)
+
+    # ------------------------------------------------------------------ sparsity
+    def set_threshold(self, threshold):                                   # sindy.py:192-194 (strict >)
+        self.Xi = self.get_Xi() if self.constraint else self.Xi
+        self.mask.data = torch.logical_and(torch.abs(self.Xi) > threshold, self.mask).float()
+
+    def reset_mask(self):                                                 # sindy.py:197-198
+        self.mask.data = torch.ones_like(self.Xi, device=self.Xi.device)
+
+    # ------------------------------------------------------------------ reporting
+    def print(self):                                                      # sindy.py:206-247
+        Xi = (self.get_Xi() if self.constraint else self.Xi).detach().cpu()
+        mask = self.mask.cpu()
+        names = library.term_names(self.latent_dim, self.poly_order, self.include_sine, self.include_exp)
+        for i in range(self.latent_dim):
+            equation = f'dz{i} ='
+            for k, name in enumerate(names):
+                if mask[i, k]:
+                    equation += f' {Xi[i, k]:.3f}' + (f'*{name}' if name else '') + ' +'
+            print(equation)
+
+    # ------------------------------------------------------------------ Gram access
+    def aug_gram(self, x, y):
+        """fp64 [Theta | y]^T [Theta | y] on the host, cached while (x, y) are unchanged."""
+        key = (x.data_ptr(), x._version, tuple(x.shape), y.data_ptr(), y._version, self.poly_order, self.flags)
+        if self._gram_cache is None or self._gram_cache[0] != key:
+            G = self.engine.aug_gram(x.reshape(-1, self.latent_dim), y.reshape(-1, self.latent_dim), self.poly_order,
+                                     self.flags)
+            self._gram_cache = (key, G.cpu().numpy())
+        return self._gram_cache[1]
+
+
+def _normal_system(regressor, G, gamma):
+    """Normal equations of the reference's (possibly block-diagonal, column-selected,
+    Q-projected) system, from the augmented Gram.  Returns (Gn, Cn, yy, m_rows, info)."""
+    d, p = regressor.latent_dim, G.shape[0] - regressor.latent_dim
+    Gtt = G[:p, :p] + (gamma * gamma) * np.eye(p)          # [Theta; gamma I]^T [Theta; gamma I]  (sindy.py:262-263)
+    Gty = G[:p, p:]                                         # Theta^T y
+    yy = np.trace(G[p:, p:])
+    return Gtt, Gty, yy, d, p
+
+
+def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
+    '''
+    Solve  argmin_w ||y - w Theta(x)||^2 + w_sindy_reg^2 ||w||^2  on the current support, then
+    threshold (reference sindy.py:250-315; note the ridge enters as gamma*I rows => gamma^2).
+
+    Same signature, same in-place updates of Xi / beta / const / mask, same return
+    ``(residual, converged)``.  ``residual`` is the squared residual of the solved system
+    averaged as the reference does (``lm.residuals.mean() / N``) -- the reference's CPU path
+    returns NaN there (empty ``residuals`` with the gelsy driver), its GPU path this number.
+    '''
+    N = x.reshape(-1, regressor.latent_dim).shape[0]
+    G = regressor.aug_gram(x, y)
+    Gtt, Gty, yy, d, p = _normal_system(regressor, G, float(w_sindy_reg))
+    driver = kwargs.get("lstsq_driver", regressor.lstsq_driver)
+    mask = (regressor.mask > 0.0).cpu().numpy()
+    dev = regressor.mask.device
+    prev_mask = regressor.mask.clone()
+
+    if mask.all() and not regressor.constraint:
+        W, _ = lstsq_normal(Gtt, Gty, N + p, driver)                       # (p, d); sindy.py:288, 300
+        res = np.array([G[p + j, p + j] - 2 * W[:, j] @ Gty[:, j] + W[:, j] @ Gtt @ W[:, j] for j in range(d)])
+        regressor.Xi.data = torch.from_numpy(W.T.copy()).float().to(dev)
+        residual = res.mean()
+    else:
+        # block-diagonal system over all equations, equation-major flattening (sindy.py:270-274)
+        flat = mask.reshape(-1)
+        Gb = np.zeros((d * p, d * p))
+        for j in range(d):
+            Gb[j * p:(j + 1) * p, j * p:(j + 1) * p] = Gtt
+        cb = Gty.T.reshape(-1)                                              # index j*p + k
+        Gm, cm = Gb[flat][:, flat], cb[flat]
+        m_rows = d * (N + p)
+        if not regressor.constraint:
+            w, _ = lstsq_normal(Gm, cm, m_rows, driver)
+            new_coef = np.zeros((d, p))
+            new_coef[mask] = w                                              # sindy.py:296-298
+            regressor.Xi.data = torch.from_numpy(new_coef).float().to(dev)
+            residual = yy - 2 * w @ cm + w @ Gm @ w
+        else:
+            Q = regressor.Q.detach().cpu().double().numpy()
+            if regressor.allow_constant:                                    # sindy.py:277-280
+                Q = np.concatenate([Q, np.zeros((Q.shape[0], d))], axis=1)
+                for i in range(d):
+                    Q[i * Q.shape[0] // d, Q.shape[1] - d + i] = 1.0
+            Qm = Q[flat]                                                    # sindy.py:282 (equation-major rows)
+            # the reference drops columns of A @ Q[mask] that are exactly zero (sindy.py:284);
+            # with a full-column-rank masked library that is a zero column of Q[mask]
+            effective = np.any(Qm != 0.0, axis=0)
+            Qe = Qm[:, effective]
+            Gq, cq = Qe.T @ Gm @ Qe, Qe.T @ cm
+            b, _ = lstsq_normal(Gq, cq, m_rows, driver)
+            full = np.zeros(Q.shape[1])
+            full[effective] = b
+            if not regressor.allow_constant:                                # sindy.py:302-305
+                regressor.beta.data = torch.from_numpy(full).float().to(dev)
+            else:                                                           # sindy.py:307-311
+                regressor.beta.data = torch.from_numpy(full[:-d].copy()).float().to(dev)
+                regressor.const.data = torch.from_numpy(full[-d:].copy()).float().view(-1, 1).to(dev)
+            residual = yy - 2 * b @ cq + b @ Gq @ b
+    regressor.set_threshold(st_threshold)                                   # sindy.py:312
+    converged = torch.allclose(prev_mask, regressor.mask)                   # sindy.py:313
+    return torch.tensor(residual / N, dtype=torch.float32, device=dev), converged
+
+
+def solve_SINDy(regressor, x, y, w_sindy_reg, st_threshold, max_iter=5, **kwargs):
+    """reference sindy.py:318-324"""
+    regressor.reset_mask()
+    residual = None
+    for _ in range(max_iter):
+        residual, converged = solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs)
+        if converged:
+            break
+    return residual

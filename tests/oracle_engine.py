@@ -1,0 +1,84 @@
+"""Test double: an engine with HipEngine's interface backed by the CPU oracle.
+
+Lives under tests/ on purpose: it lets the ``-m "not gpu"`` suite drive the product's HOST
+logic (STLSQ from the Gram, constraint handling, trainer control flow, sharding) without a
+GPU.  The product never imports it; its only engine is the HIP one.
+"""
+import torch
+
+from oracle import sindy_oracle as O
+
+
+def _fl(flags):
+    return bool(flags & 1), bool(flags & 2)
+
+
+class OracleEngine:
+    def lib_size(self, d, order, flags):
+        return O.term_count(d, order, *_fl(flags))
+
+    def theta(self, x, order, flags=0):
+        return O.theta(x, order, *_fl(flags))
+
+    def forward(self, x, xi, mask, order, flags=0):
+        m = torch.ones_like(xi) if mask is None else mask
+        return O.forward(x, xi, m, order, *_fl(flags))
+
+    def forward_jvp(self, x, v, xi, mask, order, flags=0, need_out=True):
+        m = torch.ones_like(xi) if mask is None else mask
+        out, jv = torch.autograd.functional.jvp(lambda a: O.forward(a, xi, m, order, *_fl(flags)), x, v)
+        return out, jv
+
+    def vjp(self, x, g, xi, mask, order, flags=0, need_grad_x=True):
+        m = torch.ones_like(xi) if mask is None else mask
+        xx = x.detach().clone().requires_grad_(True)
+        w = xi.detach().clone().requires_grad_(True)
+        out = O.forward(xx, w, m, order, *_fl(flags))
+        gx, gw = torch.autograd.grad(out, (xx, w), g)
+        return (gx if need_grad_x else None), gw
+
+    def odeint(self, x, xi, mask, order, flags, n_steps, dt, method="euler"):
+        m = torch.ones_like(xi) if mask is None else mask
+        f = lambda a: O.forward(a, xi, m, order, *_fl(flags))  # noqa: E731
+        return O.odeint(f, x, n_steps * dt + 0.5 * dt, dt, method) if n_steps > 0 else x.clone()
+
+    def loss_grad(self, x, dx, xi, mask, order, flags=0, inv_count=None, out=None):
+        batched = x.dim() == 3
+        X, DX = (x, dx) if batched else (x[None], dx[None])
+        S, n, d = X.shape
+        XI = xi.reshape(S, d, -1)
+        M = torch.ones_like(XI) if mask is None else mask.reshape(S, d, -1)
+        losses, grads = [], []
+        for s in range(S):
+            l, g = O.mse_loss_and_grad(X[s], DX[s], XI[s], M[s], order, *_fl(flags))
+            scale = 1.0 if inv_count is None else inv_count * n * d
+            losses.append(l * scale)
+            grads.append(g * scale)
+        loss, grad = torch.stack(losses), torch.stack(grads)
+        return (loss, grad) if batched else (loss[0], grad[0])
+
+    def aug_gram(self, x, dx, order, flags=0):
+        batched = x.dim() == 3
+        X, DX = (x, dx) if batched else (x[None], dx[None])
+        out = []
+        for s in range(X.shape[0]):
+            A = torch.cat([O.theta(X[s], order, *_fl(flags)), DX[s]], dim=1).double()
+            out.append(A.T @ A)
+        G = torch.stack(out)
+        return G if batched else G[0]
+
+    def symreg_linear(self, z, xi, mask, L, order, flags=0):
+        d = z.shape[-1]
+        reg = O.OracleRegressor(d, order, *_fl(flags), Xi0=xi)
+        reg.mask = torch.ones_like(xi) if mask is None else mask
+        loss = O.symreg_linear_latent(z, list(L.reshape(-1, d, d)), reg)
+        loss.backward()
+        return loss.detach(), reg.Xi.grad
+
+    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0):
+        d = x.shape[-1]
+        reg = O.OracleRegressor(d, order, *_fl(flags), Xi0=xi)
+        reg.mask = torch.ones_like(xi) if mask is None else mask
+        loss = O.symreg_reversed_precomputed(x, list(gx), list(jgx), reg)
+        loss.backward()
+        return loss.detach(), reg.Xi.grad

@@ -1,0 +1,124 @@
+"""GPU parity of the operator layer (SINDyRegression / solve_SINDy*) against golden vectors
+and the oracle, through the real HIP engine."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sindy_oracle as O
+from tests.helpers import t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import symode_amd
+    assert torch.cuda.is_available()
+    return symode_amd
+
+
+def make(S, d, order, sine=False, exp=False, L_list=(), thr=0.05, cc=False):
+    return S.SINDyRegression(d, order, sine, exp, L_list=list(L_list), threshold=thr, device="cuda:0", constrain_constant=cc)
+
+
+def test_stlsq_golden_on_gpu(S, golden):
+    g = golden("f3_stlsq")
+    for tag in g["cases"]:
+        d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+        gamma, thr = [float(v) for v in g[f"{tag}_hp"]]
+        x, dx = t(g[f"{tag}_x"]).cuda(), t(g[f"{tag}_dx"]).cuda()
+        r = make(S, d, order, bool(sine), bool(exp), thr=thr)
+        for wm, wx, wc in zip(g[f"{tag}_masks"], g[f"{tag}_xis"], g[f"{tag}_conv"]):
+            res, c = S.solve_SINDy_one_step(r, x, dx, gamma, thr)
+            assert np.array_equal(r.mask.cpu().numpy(), wm), tag                 # identical sparsity mask
+            assert np.allclose(r.Xi.detach().cpu().numpy(), wx, rtol=1e-5, atol=2e-5 * np.abs(wx).max()), tag
+            assert bool(c) == bool(wc) and res.is_cuda and torch.isfinite(res)
+        r2 = make(S, d, order, bool(sine), bool(exp), thr=thr)
+        S.solve_SINDy(r2, x, dx, gamma, thr)
+        assert np.array_equal(r2.mask.cpu().numpy(), g[f"{tag}_solve_mask"]), tag
+
+
+@pytest.mark.parametrize("tag", ["solve_dosc_so2", "solve_dosc_so2_o3_cc", "solve_growth_scaling2", "solve_growth_scaling2_ac"])
+def test_constrained_stlsq_golden_on_gpu(S, golden, tag):
+    g = golden("f5_constraint")
+    d, order, cc = [int(v) for v in g[f"{tag}_cfg"]]
+    gamma, thr = [float(v) for v in g[f"{tag}_hp"]]
+    x, dx = t(g[f"{tag}_x"]).cuda(), t(g[f"{tag}_dx"]).cuda()
+    r = make(S, d, order, L_list=[t(g[f"{tag}_L"])], thr=thr, cc=bool(cc))
+    r.Q = t(g[f"{tag}_Q"]).cuda()
+    for wm, wx in zip(g[f"{tag}_masks"], g[f"{tag}_xis"]):
+        S.solve_SINDy_one_step(r, x, dx, gamma, thr)
+        assert np.array_equal(r.mask.cpu().numpy(), wm)
+        assert np.allclose(r.get_Xi().detach().cpu().numpy(), wx, rtol=1e-5, atol=2e-5 * np.abs(wx).max())
+
+
+@pytest.mark.parametrize("tag", ["o3", "o2e", "d3o2s"])
+def test_forward_autograd_and_fused_mse(S, golden, tag):
+    g = golden("f2_fwd_loss_grad")
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    r = make(S, d, order, bool(sine), bool(exp))
+    r.Xi.data = t(g[f"{tag}_Xi"]).cuda()
+    r.mask = t(g[f"{tag}_mask"]).cuda()
+    x, dx = t(g[f"{tag}_x"]).cuda(), t(g[f"{tag}_dx"]).cuda()
+    # generic autograd route: forward kernel + vjp kernel, loss assembled by torch
+    loss = torch.nn.MSELoss()(r(x), dx) + 0.05 * sum(torch.norm(p, 1) for p in r.parameters())
+    loss.backward()
+    assert np.isclose(loss.item(), float(g[f"{tag}_loss"]) + 0.05 * float(g[f"{tag}_l1"]), rtol=1e-5)
+    scale = np.abs(g[f"{tag}_grad_total"]).max()
+    assert np.allclose(r.Xi.grad.cpu().numpy(), g[f"{tag}_grad_total"], rtol=1e-4, atol=2e-5 * scale)
+    # fused route
+    r.Xi.grad = None
+    lf = r.mse_loss(x, dx)
+    lf.backward()
+    assert np.isclose(lf.item(), float(g[f"{tag}_loss"]), rtol=1e-5)
+    assert np.allclose(r.Xi.grad.cpu().numpy(), g[f"{tag}_grad_mse"], rtol=1e-4, atol=2e-5 * np.abs(g[f"{tag}_grad_mse"]).max())
+
+
+def test_vjp_and_jvp_against_torch_autograd(S):
+    torch.manual_seed(4)
+    for d, order, sine, exp in [(2, 3, False, False), (2, 5, False, False), (3, 2, True, True), (1, 4, True, False), (4, 3, False, True)]:
+        r = make(S, d, order, sine, exp)
+        r.mask = (torch.rand_like(r.mask) > 0.2).float()
+        x = (torch.randn(777, d) * 0.7)
+        gout, v = torch.randn(777, d), torch.randn(777, d)
+        xg = x.cuda().requires_grad_(True)
+        out = r(xg)
+        out.backward(gout.cuda())
+        # oracle in fp64
+        xo = x.double().requires_grad_(True)
+        Xi = r.Xi.detach().cpu().double().requires_grad_(True)
+        oo = O.forward(xo, Xi, r.mask.cpu().double(), order, sine, exp)
+        oo.backward(gout.double())
+        assert torch.allclose(out.detach().cpu().double(), oo.detach(), rtol=1e-4, atol=1e-5 * oo.abs().max().item())
+        assert torch.allclose(xg.grad.cpu().double(), xo.grad, rtol=1e-4, atol=1e-5 * xo.grad.abs().max().item())
+        assert torch.allclose(r.Xi.grad.cpu().double(), Xi.grad, rtol=1e-4, atol=1e-5 * Xi.grad.abs().max().item())
+        _, jv = torch.autograd.functional.jvp(lambda a: O.forward(a, Xi.detach(), r.mask.cpu().double(), order, sine, exp), x.double(), v.double())
+        got = r.jvp(x.cuda(), v.cuda()).cpu().double()
+        assert torch.allclose(got, jv, rtol=1e-4, atol=1e-5 * jv.abs().max().item())
+
+
+def test_constrained_forward_gradients_reach_beta(S, golden):
+    g = golden("f4_lbfgs")
+    tag = "dosc_esindy"
+    x, dx = t(g[f"{tag}_x"]).cuda(), t(g[f"{tag}_dx"]).cuda()
+    r = make(S, 2, 2, L_list=[torch.tensor([[0.0, 1.0], [-1.0, 0.0]])], thr=0.01)
+    r.Q = t(g[f"{tag}_Q"]).cuda()
+    r.beta.data, r.const.data = t(g[f"{tag}_init_beta"]).cuda(), t(g[f"{tag}_init_const"]).cuda()
+    loss = r.mse_loss(x, dx)
+    loss.backward()
+    reg = O.OracleRegressor(2, 2, L_list=[torch.tensor([[0.0, 1.0], [-1.0, 0.0]])], beta0=t(g[f"{tag}_init_beta"]), const0=t(g[f"{tag}_init_const"]))
+    reg.Q = t(g[f"{tag}_Q"])
+    lo = torch.nn.functional.mse_loss(reg(t(g[f"{tag}_x"])), t(g[f"{tag}_dx"]))
+    lo.backward()
+    assert np.isclose(loss.item(), lo.item(), rtol=1e-5)
+    assert torch.allclose(r.beta.grad.cpu(), reg.beta.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(r.const.grad.cpu(), reg.const.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_eval_theta_and_leading_dims(S):
+    r = make(S, 2, 3)
+    x = torch.randn(5, 7, 2)
+    assert torch.equal(r.eval_Theta_at(x.cuda()).cpu(), O.theta(x, 3))
+    assert r(x.cuda()).shape == (5, 7, 2)
+    with pytest.raises(S.SymodeError):
+        r(x)            # CPU input: no fallback

@@ -272,7 +272,7 @@ def f5_constraint():
     # constrained solve_SINDy on clean damped-oscillator data (so2) and growth data (scaling2)
     for tag, sysname, Lname, order, cc, gamma, thr in [
         ("solve_dosc_so2", "dosc", "so2", 2, False, 0.0, 0.01),
-        ("solve_dosc_so2_o3_cc", "dosc", "so2", 3, True, 0.05, 0.01),
+        ("solve_dosc_so2_o3_cc", "dosc", "so2", 3, True, 0.05, 1e-9),
         ("solve_growth_scaling2", "growth", "scaling2", 2, True, 0.0, 0.05),
         ("solve_growth_scaling2_ac", "growth", "scaling2", 2, False, 0.0, 0.05),
     ]:
@@ -294,6 +294,31 @@ def f5_constraint():
                        f"{tag}_use_kron": np.array(r.use_kron_product),
                        f"{tag}_masks": torch.stack(masks), f"{tag}_xis": torch.stack(xis), f"{tag}_conv": np.array(conv),
                        f"{tag}_cfg": np.array([2, order, int(cc)]), f"{tag}_hp": np.array([gamma, thr])})
+    # Rank-deficient constrained system (so2, order 3, support = linear terms): three of the four
+    # columns of A @ Q[mask] are collinear.  torch 2.10's CPU gelsy path is NOT reproducible on
+    # it (identical calls return rank 1 or rank 2), so the fixture stores the explicit system,
+    # the outcomes of 12 repeated reference-driver calls and the SVD-driver (gelsd) solution.
+    x, dx = _system_data("dosc", 10, 2000, 10, 0.02, 0.0, seed=13)
+    torch.manual_seed(3)
+    r = make_regressor(2, 3, L_list=[gens["so2"]], threshold=0.01, constrain_constant=True)
+    th = r.eval_Theta_at(x)
+    A = torch.cat([th, 0.05 * torch.eye(10)], 0)
+    B = torch.cat([dx, torch.zeros(10, 2)], 0)
+    m = torch.zeros(2, 10, dtype=torch.bool)
+    m[:, 1] = True
+    m[:, 2] = True
+    AQ = torch.block_diag(A, A)[:, m.flatten()] @ r.Q[m.flatten()]
+    Bf = B.T.reshape(-1)
+    outs = []
+    for i in range(12):
+        _junk = torch.randn(1000 + 37 * i)
+        lm = torch.linalg.lstsq(AQ, Bf)
+        outs.append(np.concatenate([[float(lm.rank)], lm.solution.numpy()]))
+    arrays["rankdef_G"] = AQ.double().T @ AQ.double()
+    arrays["rankdef_C"] = AQ.double().T @ Bf.double()
+    arrays["rankdef_rows"] = np.array(AQ.shape[0])
+    arrays["rankdef_gelsy_outcomes"] = np.stack(outs)
+    arrays["rankdef_gelsd"] = torch.linalg.lstsq(AQ, Bf, driver="gelsd").solution
     arrays["cases"] = np.array(cases)
     save("f5_constraint", **arrays)
 
