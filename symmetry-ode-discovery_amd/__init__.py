@@ -6,7 +6,7 @@ root-level shim ``symode_amd.py`` is on the path, simply ``import symode_amd``.
 """
 import sys as _sys
 
-from . import constraint, engine, library, lstsq, sindy  # noqa: F401
+from . import batched, constraint, data, engine, library, lstsq, sindy  # noqa: F401
 from .engine import FLAG_EXP, FLAG_SINE, HipEngine, SymodeError, get_engine, library_flags  # noqa: F401
 
 from .sindy import SINDyRegression, solve_SINDy, solve_SINDy_one_step  # noqa: F401

@@ -1,0 +1,94 @@
+"""Batched / sharded evaluation of the SINDy closure over independent (trajectory, seed) problems.
+
+One process per GPU.  Every rank keeps, resident in HBM, its shard of the points of each of S
+problems: x, dx (S, N_local, d).  One call evaluates loss and gradient of all S problems with
+the fused Theta + residual + gradient kernel and, when a process group is given, sums the
+per-rank partials with ONE all-reduce per chunk of problems (RCCL over xGMI when the backend
+is "nccl"); chunks are pipelined so the collective of chunk c overlaps the kernel of chunk
+c+1.  The message is S*(1 + d*p) floats -- latency-bound, hence few, fused collectives.
+
+The reference runs one process per seed and has no distributed code (run_scripts/*.sh loop
+over seeds); this is the new design SURVEY section 8(e) calls point-sharding.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .engine import get_engine, library_flags
+
+
+class BatchedClosure:
+    def __init__(self, x, dx, poly_order, include_sine=False, include_exp=False, Q=None, use_kron_product=True,
+                 allow_constant=True, group=None, world_size=None, n_chunks=1, engine=None):
+        assert x.dim() == 3 and x.shape == dx.shape, "x, dx must be (S, N_local, d)"
+        self.engine = engine or get_engine()
+        self.x, self.dx = x.contiguous(), dx.contiguous()
+        self.S, self.n_local, self.d = x.shape
+        self.order = poly_order
+        self.flags = library_flags(include_sine, include_exp)
+        self.p = self.engine.lib_size(self.d, poly_order, self.flags)
+        self.Q = Q
+        self.use_kron, self.allow_constant = use_kron_product, allow_constant
+        self.group = group
+        self.distributed = group is not None or (world_size or 1) > 1
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if self.distributed else 1)
+        self.n_global = self.n_local * self.world            # equal shards (weak scaling)
+        self.inv_count = 1.0 / (self.n_global * self.d)
+        self.n_chunks = max(1, min(n_chunks, self.S))
+        nacc = 1 + self.d * self.p
+        # packed [loss | grad] per chunk so that one collective carries both
+        bounds = torch.linspace(0, self.S, self.n_chunks + 1).long().tolist()
+        self.chunks = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+        self.buffers = [torch.empty((b - a) * nacc, dtype=torch.float32, device=x.device) for a, b in self.chunks]
+
+    # -- coefficient plumbing (batched get_Xi, sindy.py:169-176) ----------------------------
+    def xi_from(self, beta, const=None):
+        if self.Q is None:
+            return beta                                         # beta IS Xi (S, d, p)
+        flat = beta @ self.Q.T                                  # (S, d*p)
+        Xi = flat.view(self.S, self.d, self.p) if self.use_kron else flat.view(self.S, self.p, self.d).transpose(1, 2)
+        if self.allow_constant and const is not None:
+            Xi = Xi.clone()
+            Xi[:, :, 0:1] += const
+        return Xi.contiguous()
+
+    def grads_to(self, grad_xi):
+        if self.Q is None:
+            return grad_xi, None
+        g = grad_xi if self.use_kron else grad_xi.transpose(1, 2)
+        g_beta = g.reshape(self.S, -1) @ self.Q
+        g_const = grad_xi[:, :, 0:1].clone() if self.allow_constant else None
+        return g_beta, g_const
+
+    # -- the hot path -------------------------------------------------------------------------
+    def loss_grad_xi(self, Xi, mask=None):
+        """loss (S,), dloss/dXi (S, d, p) summed over all ranks' shards."""
+        works = []
+        for (a, b), buf in zip(self.chunks, self.buffers):
+            n = b - a
+            loss = buf[:n]
+            grad = buf[n:].view(n, self.d, self.p)
+            self.engine.loss_grad(self.x[a:b], self.dx[a:b], Xi[a:b], None if mask is None else mask[a:b], self.order,
+                                  self.flags, inv_count=self.inv_count, out=(loss, grad))
+            if self.distributed:
+                works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        loss = torch.cat([buf[:b - a] for (a, b), buf in zip(self.chunks, self.buffers)])
+        grad = torch.cat([buf[b - a:].view(b - a, self.d, self.p) for (a, b), buf in zip(self.chunks, self.buffers)])
+        return loss, grad
+
+    def evaluate(self, beta, const=None, mask=None):
+        """Closure of all S problems: (loss (S,), d/dbeta, d/dconst)."""
+        Xi = self.xi_from(beta, const)
+        loss, grad = self.loss_grad_xi(Xi, mask)
+        g_beta, g_const = self.grads_to(grad)
+        return loss, g_beta, g_const
+
+    def aug_gram(self):
+        """fp64 (S, p+d, p+d) augmented Gram matrices, all-reduced over the point shards."""
+        G = self.engine.aug_gram(self.x, self.dx, self.order, self.flags)
+        if self.distributed:
+            dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group)
+        return G

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "library.hpp"
 #include "points.hpp"
 #include "reduce.hpp"
@@ -38,9 +40,15 @@ struct LibOps {
 // ---------------------------------------------------------------------------------------
 
 // Grid width for a streaming pass over n points (per problem), S problems on grid.y.
+// Small problems favour latency: one step per thread until every CU has two blocks; beyond that,
+// at least 4 steps per thread so the reduction epilogue amortises.
 inline int grid_x_for(long n, long S, int pts_per_thread_iter) {
-    const long per_block = (long)BLOCK * pts_per_thread_iter * 4;   // >= 4 iterations per thread
+    const long per_block = (long)BLOCK * pts_per_thread_iter;
     long g = (n + per_block - 1) / per_block;
+    if (g > 512) {
+        g = (n + 4 * per_block - 1) / (4 * per_block);
+        if (g < 512) g = 512;
+    }
     long cap = MAX_GRID_X / (S < 1 ? 1 : S);
     if (cap < 2) cap = 2;
     if (g > cap) g = cap;
@@ -208,9 +216,9 @@ __global__ __launch_bounds__(BLOCK) void odeint_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------
 template <int NACC>
 __device__ __forceinline__ void emit_partials(float (&acc)[NACC], double* __restrict__ ws) {
-    __shared__ float lds[(BLOCK / WAVE) * NACC];
+    __shared__ float lds[reduce_lds_floats(BLOCK)];
     double* dst = ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * NACC;
-    block_reduce_emit<NACC, BLOCK>(acc, lds, [&](int k, double v) { dst[k] = v; });
+    block_reduce_emit_lds<NACC, BLOCK>(acc, lds, [&](int k, double v) { dst[k] = v; });
 }
 
 // out[0] = loss_scale * sum_0 ; grad[k-1] = grad_scale * sum_k * mask[k-1]
@@ -220,14 +228,32 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
                                                          const float* __restrict__ mask, float loss_scale,
                                                          float grad_scale, float* __restrict__ loss,
                                                          float* __restrict__ grad) {
+    // thread (part, lane): value k = k0 + lane, blocks g = part, part + 4, ... (coalesced rows of the
+    // partial matrix); the 4 parts are combined in fixed order through LDS.
+    __shared__ double comb[BLOCK];
     const long s = blockIdx.x;
     const double* src = ws + s * (long)G * nacc;
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    for (int k = wave; k < nacc; k += BLOCK / WAVE) {
+    const int lane = threadIdx.x & (WAVE - 1), part = threadIdx.x / WAVE;
+    for (int k0 = 0; k0 < nacc; k0 += WAVE) {
+        const int k = k0 + lane;
         double v = 0.0;
-        for (int g = lane; g < G; g += WAVE) v += src[(long)g * nacc + k];
-        v = wave_sum(v);
-        if (lane == 0) {
+        if (k < nacc) {
+            constexpr int NP_ = BLOCK / WAVE, U = 16;
+            int g = part;
+            for (; g + (U - 1) * NP_ < G; g += U * NP_) {      // 16 independent loads in flight, added in order
+                double t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[u] = src[(long)(g + u * NP_) * nacc + k];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v += t[u];
+            }
+            for (; g < G; g += NP_) v += src[(long)g * nacc + k];
+        }
+        if (k0 > 0) __syncthreads();
+        comb[threadIdx.x] = v;
+        __syncthreads();
+        if (part == 0 && k < nacc) {
+            v = comb[lane] + comb[WAVE + lane] + comb[2 * WAVE + lane] + comb[3 * WAVE + lane];
             if (k == 0) {
                 if (loss != nullptr) loss[s] = (float)(v * (double)loss_scale);
             } else {
@@ -242,11 +268,15 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 // ---------------------------------------------------------------------------------------
 // K1: fused Theta + residual + MSE + gradient                  (closure body + backward)
 // ---------------------------------------------------------------------------------------
-template <class Lib>
+// VARIANT selects the streaming schedule (kept as a template knob for A/B runs on the GPU):
+//   0 plain grid-stride loop; 1 software prefetch of the next chunk; 2 two chunks per step;
+//   3 = 1 with non-temporal loads; 4 = 2 with non-temporal loads.
+template <class Lib, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                           long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, double* __restrict__ ws) {
-    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NACC = 1 + D * P;
+    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
+    constexpr bool NT = (VARIANT == 3 || VARIANT == 4);
     const long s = blockIdx.y;
     const float* xs = x + s * N * D;
     const float* ys = dx + s * N * D;
@@ -270,21 +300,75 @@ __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(r[j], th[k], acc[1 + j * P + k]);
     };
-    for_each_point<D, BLOCK>(
-        N, vec,
-        [&](long c) {
-            float xp[PPT][D], yp[PPT][D];
-            load_chunk<D>(xs, c, xp);
-            load_chunk<D>(ys, c, yp);
+    auto chunk = [&](const float4 (&vx)[NV], const float4 (&vy)[NV]) {
+        float xp[PPT][D], yp[PPT][D];
+        unpack_chunk<D>(vx, xp);
+        unpack_chunk<D>(vy, yp);
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) one(xp[i], yp[i]);
-        },
-        [&](long n) {
-            float xp[D], yp[D];
-            load_point<D>(xs, n, xp);
-            load_point<D>(ys, n, yp);
-            one(xp, yp);
-        });
+        for (int i = 0; i < PPT; ++i) one(xp[i], yp[i]);
+    };
+    auto point = [&](long n) {
+        float xp[D], yp[D];
+        load_point<D>(xs, n, xp);
+        load_point<D>(ys, n, yp);
+        one(xp, yp);
+    };
+
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
+    const long nthreads = (long)gridDim.x * BLOCK;
+    if (vec) {
+        const long nchunks = N / PPT;
+        long c = tid;
+        if constexpr (VARIANT == 1 || VARIANT == 3) {
+            float4 cx[NV], cy[NV];
+            if (c < nchunks) {
+                load_chunk_raw<D, NT>(xs, c, cx);
+                load_chunk_raw<D, NT>(ys, c, cy);
+            }
+            while (c < nchunks) {
+                const long cn = c + nthreads;
+                float4 nx[NV], ny[NV];
+                if (cn < nchunks) {
+                    load_chunk_raw<D, NT>(xs, cn, nx);
+                    load_chunk_raw<D, NT>(ys, cn, ny);
+                }
+                chunk(cx, cy);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    cx[i] = nx[i];
+                    cy[i] = ny[i];
+                }
+                c = cn;
+            }
+        } else if constexpr (VARIANT == 2 || VARIANT == 4) {
+            for (; c + nthreads < nchunks; c += 2 * nthreads) {
+                float4 ax[NV], ay[NV], bx[NV], by[NV];
+                load_chunk_raw<D, NT>(xs, c, ax);
+                load_chunk_raw<D, NT>(ys, c, ay);
+                load_chunk_raw<D, NT>(xs, c + nthreads, bx);
+                load_chunk_raw<D, NT>(ys, c + nthreads, by);
+                chunk(ax, ay);
+                chunk(bx, by);
+            }
+            if (c < nchunks) {
+                float4 ax[NV], ay[NV];
+                load_chunk_raw<D, NT>(xs, c, ax);
+                load_chunk_raw<D, NT>(ys, c, ay);
+                chunk(ax, ay);
+            }
+        } else {
+            for (; c < nchunks; c += nthreads) {
+                float4 ax[NV], ay[NV];
+                load_chunk_raw<D, false>(xs, c, ax);
+                load_chunk_raw<D, false>(ys, c, ay);
+                chunk(ax, ay);
+            }
+        }
+        const long n = nchunks * PPT + tid;
+        if (n < N) point(n);
+    } else {
+        for (long n = tid; n < N; n += nthreads) point(n);
+    }
     emit_partials<NACC>(acc, ws);
 }
 
@@ -523,12 +607,27 @@ hipError_t launch_odeint(const float* x, long n, const float* xi, const float* m
     return hipSuccess;
 }
 
+inline int loss_grad_variant() {
+    static const int v = [] {
+        const char* e = getenv("SYMODE_LOSS_GRAD_VARIANT");
+        return e ? atoi(e) : 4;
+    }();
+    return v;
+}
+
 template <class Lib>
 hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, const float* xi, const float* mask,
                             float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
     const bool vec = vec_ok(x, n, Lib::D, S) && vec_ok(dx, n, Lib::D, S);
-    loss_grad_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, vec, xi, mask, ws);
+    const dim3 grid(gx, (unsigned)S), block(BLOCK);
+    switch (loss_grad_variant()) {
+        case 1: loss_grad_kernel<Lib, 1><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
+        case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
+        case 3: loss_grad_kernel<Lib, 3><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
+        case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
+        default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
+    }
     SYMODE_LAUNCH_CHECK();
     finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv_count, 2.0f * inv_count, loss,
                                                                grad);

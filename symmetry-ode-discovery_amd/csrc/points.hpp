@@ -32,6 +32,38 @@ __device__ __forceinline__ void load_chunk(const float* __restrict__ a, long c, 
     for (int i = 0; i < NV * 4; ++i) p[i / D][i % D] = f[i];
 }
 
+// Raw 16-byte vectors of chunk c (optionally non-temporal: the stream is read exactly once).
+template <int D, bool NT>
+__device__ __forceinline__ void load_chunk_raw(const float* __restrict__ a, long c, float4 (&v)[Chunk<D>::NV]) {
+    constexpr int NV = Chunk<D>::NV;
+    const float4* q = reinterpret_cast<const float4*>(a) + c * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if constexpr (NT) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q + i));
+            v[i] = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            v[i] = q[i];
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void unpack_chunk(const float4 (&v)[Chunk<D>::NV], float (&p)[Chunk<D>::PPT][D]) {
+    constexpr int NV = Chunk<D>::NV;
+    float f[NV * 4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f[4 * i + 0] = v[i].x;
+        f[4 * i + 1] = v[i].y;
+        f[4 * i + 2] = v[i].z;
+        f[4 * i + 3] = v[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NV * 4; ++i) p[i / D][i % D] = f[i];
+}
+
 template <int D>
 __device__ __forceinline__ void store_chunk(float* __restrict__ a, long c, const float (&p)[Chunk<D>::PPT][D]) {
     constexpr int NV = Chunk<D>::NV;

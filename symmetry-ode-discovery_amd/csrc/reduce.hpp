@@ -42,4 +42,43 @@ __device__ __forceinline__ void block_reduce_emit(float (&acc)[NACC], float* lds
     }
 }
 
+// Block-level reduction through an LDS transpose (no cross-lane network):
+//   round r parks KC accumulators of all BLOCK threads as lds[kk][tid] (row stride BLOCK+1:
+//   conflict-free writes and reads); thread (part, kk) adds BLOCK/PARTS consecutive partials in
+//   fixed order; PARTS partial sums per value are combined by thread kk.  Deterministic.
+template <int NACC, int BLOCK, typename Emit>
+__device__ __forceinline__ void block_reduce_emit_lds(float (&acc)[NACC], float* lds, Emit emit) {
+    constexpr int KC = 16;                      // values per round
+    constexpr int PARTS = BLOCK / KC;           // 16 segments of BLOCK/PARTS = 16 threads' partials
+    constexpr int SEG = BLOCK / PARTS;
+    constexpr int STRIDE = BLOCK + 1;
+    float* stage = lds;                          // [KC][STRIDE]
+    float* part = lds + KC * STRIDE;             // [PARTS][KC]
+    const int tid = threadIdx.x;
+    const int kk = tid % KC, pp = tid / KC;
+#pragma unroll
+    for (int k0 = 0; k0 < NACC; k0 += KC) {
+        if (k0 > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            if (k0 + j < NACC) stage[j * STRIDE + tid] = acc[k0 + j];
+        __syncthreads();
+        float s = 0.0f;
+        if (k0 + kk < NACC) {
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) s += stage[kk * STRIDE + pp * SEG + i];
+        }
+        part[pp * KC + kk] = s;
+        __syncthreads();
+        if (tid < KC && k0 + tid < NACC) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) t += (double)part[q * KC + tid];
+            emit(k0 + tid, t);
+        }
+    }
+}
+
+constexpr int reduce_lds_floats(int block) { return 16 * (block + 1) + (block / 16) * 16; }
+
 }  // namespace symode

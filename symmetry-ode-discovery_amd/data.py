@@ -1,0 +1,99 @@
+"""Synthetic trajectories of the four benchmark systems, generated with torch on any device.
+
+Restates the reference's offline data recipe -- fixed-step RK4 over a batch of initial
+conditions (data_utils/ode.py:7-28), the four right-hand sides and their initial-condition
+samplers (data_utils/{damped_oscillator,selkov,lotka,growth}.py), additive noise scaled by the
+per-dimension std (data_utils/ode.py:33-37) -- so that benchmark inputs of any size can be made
+directly in HBM.  fp64 arithmetic like the numpy original, cast to fp32 at the end
+(dataset.py:188-189).  Not part of the hot path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def rhs_dosc(x, a=0.1):
+    return torch.stack([-a * x[..., 0] - x[..., 1], x[..., 0] - a * x[..., 1]], dim=-1)
+
+
+def rhs_selkov(x, a=0.75, b=0.1, c=0.1):
+    xy2 = x[..., 0] * x[..., 1] ** 2
+    return torch.stack([a - b * x[..., 0] - xy2, -x[..., 1] + c * x[..., 0] + xy2], dim=-1)
+
+
+def rhs_lv(x, a=2 / 3, b=4 / 3, c=1.0, d=1.0):
+    return torch.stack([a - b * torch.exp(x[..., 1]), c * torch.exp(x[..., 0]) - d], dim=-1)
+
+
+def rhs_growth(x, a=0.1, b=0.3):
+    return torch.stack([a * x[..., 1] ** 2 - b * x[..., 0], x[..., 1]], dim=-1)
+
+
+def ics_dosc(n, gen, device):
+    r = 0.5 + 1.5 * torch.rand(n, generator=gen, device=device, dtype=torch.float64)
+    th = 2 * math.pi * torch.rand(n, generator=gen, device=device, dtype=torch.float64)
+    return torch.stack([r * torch.cos(th), r * torch.sin(th)], dim=-1)
+
+
+def ics_selkov(n, gen, device):
+    return 0.5 + 0.5 * torch.rand(n, 2, generator=gen, device=device, dtype=torch.float64)
+
+
+def ics_growth(n, gen, device):
+    return 0.2 + 0.8 * torch.rand(n, 2, generator=gen, device=device, dtype=torch.float64)
+
+
+def ics_lv(n, gen, device, h_min=3.0, h_max=4.5):
+    out = torch.empty(0, 2, dtype=torch.float64, device=device)
+    while out.shape[0] < n:                       # rejection on the Hamiltonian, lotka.py:10-31
+        x0 = torch.log(torch.rand(4 * n, 2, generator=gen, device=device, dtype=torch.float64))
+        h = torch.exp(x0[:, 0]) - x0[:, 0] + 4 / 3 * torch.exp(x0[:, 1]) - 2 / 3 * x0[:, 1]
+        out = torch.cat([out, x0[(h >= h_min) & (h <= h_max)]])
+    return out[:n]
+
+
+SYSTEMS = {
+    # name: (rhs, initial-condition sampler, default dt)
+    "dosc": (rhs_dosc, ics_dosc, 0.02),
+    "selkov": (rhs_selkov, ics_selkov, 0.002),
+    "lv": (rhs_lv, ics_lv, 0.002),
+    "growth": (rhs_growth, ics_growth, 0.002),
+}
+
+
+def rk4_trajectories(rhs, x0, dt, num_steps):
+    """(x, dx) of shape (n_ics, num_steps, d): states and exact derivatives along RK4 orbits."""
+    x = torch.empty(num_steps, *x0.shape, dtype=x0.dtype, device=x0.device)
+    dx = torch.empty_like(x)
+    cur = x0
+    for i in range(num_steps):
+        d1 = rhs(cur)
+        x[i], dx[i] = cur, d1
+        if i == num_steps - 1:
+            break
+        k1 = dt * d1
+        k2 = dt * rhs(cur + 0.5 * k1)
+        k3 = dt * rhs(cur + 0.5 * k2)
+        k4 = dt * rhs(cur + k3)
+        cur = cur + (k1 + 2 * k2 + 2 * k3 + k4) / 6
+    return x.transpose(0, 1).contiguous(), dx.transpose(0, 1).contiguous()
+
+
+def make_dataset(name, n_ics, num_steps, dt=None, noise=0.0, seed=0, device="cpu", n_problems=1):
+    """fp32 (n_problems, n_ics*num_steps, d) trajectories and derivatives, flattened like ODEDataset
+    (dataset.py:193-194).  Every problem gets its own initial conditions and noise draw."""
+    rhs, ics, dt0 = SYSTEMS[name]
+    dt = dt0 if dt is None else dt
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    x0 = ics(n_problems * n_ics, gen, device)
+    x, dx = rk4_trajectories(rhs, x0, dt, num_steps)
+    d = x.shape[-1]
+    x = x.reshape(n_problems, n_ics * num_steps, d)
+    dx = dx.reshape(n_problems, n_ics * num_steps, d)
+    if noise > 0:
+        std = x.std(dim=1, keepdim=True)
+        x = x + noise * std * torch.randn(x.shape, generator=gen, device=device, dtype=x.dtype)
+    return x.float().contiguous(), dx.float().contiguous()
