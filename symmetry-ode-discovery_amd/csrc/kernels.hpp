@@ -268,15 +268,19 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 // ---------------------------------------------------------------------------------------
 // K1: fused Theta + residual + MSE + gradient                  (closure body + backward)
 // ---------------------------------------------------------------------------------------
-// VARIANT selects the streaming schedule (kept as a template knob for A/B runs on the GPU):
-//   0 plain grid-stride loop; 1 software prefetch of the next chunk; 2 two chunks per step;
-//   3 = 1 with non-temporal loads; 4 = 2 with non-temporal loads.
+// VARIANT selects the streaming schedule (kept as a template knob for A/B runs on the GPU,
+// SYMODE_LOSS_GRAD_VARIANT): 0 plain grid-stride loop; 2 two chunks per step; 4 = 2 with
+// non-temporal loads (default).  Measured on MI355X, S=1024 x 125000 points, d=2 (round 1):
+//   order 5: 0 -> 4.8 TB/s, 4 -> 5.3 TB/s;  order 3: 0 -> 5.6 TB/s, 4 -> 6.3 TB/s (alg. bytes).
+// A software-prefetch form (next chunk loaded before computing the current one) and forms with
+// sched_barrier between points were slower or equal; -fno-slp-vectorize (Makefile) is worth
+// 6 % at order 5: packed fp32 FMAs force the uniform coefficients out of SGPRs into VGPR pairs.
 template <class Lib, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                           long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, double* __restrict__ ws) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
-    constexpr bool NT = (VARIANT == 3 || VARIANT == 4);
+    constexpr bool NT = (VARIANT == 4);
     const long s = blockIdx.y;
     const float* xs = x + s * N * D;
     const float* ys = dx + s * N * D;
@@ -319,28 +323,7 @@ __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restric
     if (vec) {
         const long nchunks = N / PPT;
         long c = tid;
-        if constexpr (VARIANT == 1 || VARIANT == 3) {
-            float4 cx[NV], cy[NV];
-            if (c < nchunks) {
-                load_chunk_raw<D, NT>(xs, c, cx);
-                load_chunk_raw<D, NT>(ys, c, cy);
-            }
-            while (c < nchunks) {
-                const long cn = c + nthreads;
-                float4 nx[NV], ny[NV];
-                if (cn < nchunks) {
-                    load_chunk_raw<D, NT>(xs, cn, nx);
-                    load_chunk_raw<D, NT>(ys, cn, ny);
-                }
-                chunk(cx, cy);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    cx[i] = nx[i];
-                    cy[i] = ny[i];
-                }
-                c = cn;
-            }
-        } else if constexpr (VARIANT == 2 || VARIANT == 4) {
+        if constexpr (VARIANT == 2 || VARIANT == 4) {
             for (; c + nthreads < nchunks; c += 2 * nthreads) {
                 float4 ax[NV], ay[NV], bx[NV], by[NV];
                 load_chunk_raw<D, NT>(xs, c, ax);
@@ -622,9 +605,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     const bool vec = vec_ok(x, n, Lib::D, S) && vec_ok(dx, n, Lib::D, S);
     const dim3 grid(gx, (unsigned)S), block(BLOCK);
     switch (loss_grad_variant()) {
-        case 1: loss_grad_kernel<Lib, 1><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
         case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
-        case 3: loss_grad_kernel<Lib, 3><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
         case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
         default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
     }

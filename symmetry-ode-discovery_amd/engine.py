@@ -17,7 +17,7 @@ FLAG_SINE = 1
 FLAG_EXP = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsymode_hip.so")
+LIB_PATH = os.environ.get("SYMODE_LIB") or os.path.join(_HERE, "libsymode_hip.so")
 
 # name -> (restype, argtypes); kept in step with include/symode.h (tests check every symbol)
 _SIGNATURES = {
