@@ -111,6 +111,15 @@ int symode_vjp(const float* x, const float* g, long n, int d, int order, int fla
 int symode_forward_jvp(const float* x, const float* v, long n, int d, int order, int flags, const float* xi,
                        const float* mask, float* out, float* jv, void* stream);
 
+/* Reverse mode of symode_forward_jvp, given g_out = dL/d(out) (may be NULL = 0) and g_jv = dL/d(jv):
+ *   grad_x (n, d) (includes the second-order term through J_Theta(x) v), grad_v (n, d),
+ *   grad_xi (d, p) = (g_out^T Theta + g_jv^T (J_Theta v)) * mask.
+ * replaces: the backward of the create_graph=True jvp in model_utils.py:32, 56 (what makes the
+ * reference need a twice-differentiable regressor). */
+int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const float* g_jv, long n, int d, int order,
+                   int flags, const float* xi, const float* mask, float* grad_x, float* grad_v, float* grad_xi,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,10 +6,11 @@ root-level shim ``symode_amd.py`` is on the path, simply ``import symode_amd``.
 """
 import sys as _sys
 
-from . import batched, constraint, data, engine, library, lstsq, sindy  # noqa: F401
+from . import (autoencoder, batched, constraint, data, dataset, engine, evaluation, library, lie, lstsq, model_utils,  # noqa: F401
+               parser_utils, sindy, train)
 from .engine import FLAG_EXP, FLAG_SINE, HipEngine, SymodeError, get_engine, library_flags  # noqa: F401
 
-from .sindy import SINDyRegression, solve_SINDy, solve_SINDy_one_step  # noqa: F401
+from .sindy import SINDyRegression, WSINDyWrapper, solve_SINDy, solve_SINDy_one_step  # noqa: F401
 
 __all__ = ["engine", "SINDyRegression", "solve_SINDy", "solve_SINDy_one_step", "HipEngine", "SymodeError", "get_engine", "library_flags", "FLAG_SINE", "FLAG_EXP"]
 

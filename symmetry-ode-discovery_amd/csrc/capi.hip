@@ -182,4 +182,19 @@ int symode_forward_jvp(const float* x, const float* v, long n, int d, int order,
     return (int)ops->forward_jvp(x, v, n, xi, mask, out, jv, (hipStream_t)stream);
 }
 
+int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const float* g_jv, long n, int d, int order,
+                   int flags, const float* xi, const float* mask, float* grad_x, float* grad_v, float* grad_xi,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 1) return SYMODE_E_BADSIZE;
+    if (!x || !v || !g_jv || !xi || !grad_x || !grad_v || !grad_xi) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(v, 4) || misaligned(g_out, 4) || misaligned(g_jv, 4) || misaligned(xi, 4) ||
+        misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
+        return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(1, n);
+    const int gx = grid_x_for(n, 1, 1);
+    return (int)ops->jvp_vjp(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, grad_xi, (double*)workspace, gx,
+                             (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -33,6 +33,9 @@ struct LibOps {
                       float* grad_xi, double* ws, int gx, hipStream_t st);
     hipError_t (*forward_jvp)(const float* x, const float* v, long n, const float* xi, const float* mask, float* out,
                               float* jv, hipStream_t st);
+    hipError_t (*jvp_vjp)(const float* x, const float* v, const float* g_out, const float* g_jv, long n, const float* xi,
+                          const float* mask, float* grad_x, float* grad_v, float* grad_xi, double* ws, int gx,
+                          hipStream_t st);
 };
 
 // ---------------------------------------------------------------------------------------
@@ -551,6 +554,52 @@ __global__ __launch_bounds__(BLOCK) void forward_jvp_kernel(const float* __restr
     }
 }
 
+// Reverse mode of forward_jvp_kernel: upstream g_out on out (may be null) and g_jv on jv.
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                        const float* __restrict__ g_out,
+                                                        const float* __restrict__ g_jv, long N,
+                                                        const float* __restrict__ xi, const float* __restrict__ mask,
+                                                        float* __restrict__ grad_x, float* __restrict__ grad_v,
+                                                        double* __restrict__ ws) {
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, 0, w);
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    for (long n = tid; n < N; n += nthreads) {
+        float xp[D], vp[D], go[D], gt[D], th[P], dth[P], bar[P], dbar[P], bx[D], bv[D];
+        load_point<D>(x, n, xp);
+        load_point<D>(v, n, vp);
+        load_point<D>(g_jv, n, gt);
+        if (g_out != nullptr) {
+            load_point<D>(g_out, n, go);
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; ++j) go[j] = 0.0f;
+        }
+        Lib::eval_jvp(xp, vp, th, dth);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            float a = 0.0f, c = 0.0f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                a = fmaf(go[j], w[j * P + k], a);
+                c = fmaf(gt[j], w[j * P + k], c);
+                acc[1 + j * P + k] = fmaf(go[j], th[k], fmaf(gt[j], dth[k], acc[1 + j * P + k]));
+            }
+            bar[k] = a;
+            dbar[k] = c;
+        }
+        Lib::vjp_of_jvp(xp, vp, th, dth, bar, dbar, bx, bv);
+        store_point<D>(grad_x, n, bx);
+        store_point<D>(grad_v, n, bv);
+    }
+    emit_partials<NACC>(acc, ws);
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
@@ -657,6 +706,18 @@ hipError_t launch_forward_jvp(const float* x, const float* v, long n, const floa
     if (n == 0) return hipSuccess;
     const int g = grid_x_for(n, 1, 1);
     forward_jvp_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, v, n, xi, mask, out, jv);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_jvp_vjp(const float* x, const float* v, const float* g_out, const float* g_jv, long n, const float* xi,
+                          const float* mask, float* grad_x, float* grad_v, float* grad_xi, double* ws, int gx,
+                          hipStream_t st) {
+    constexpr int NACC = 1 + Lib::D * Lib::P;
+    jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, ws);
+    SYMODE_LAUNCH_CHECK();
+    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }

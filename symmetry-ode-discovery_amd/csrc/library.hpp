@@ -135,6 +135,48 @@ struct Library {
             for (int i = 0; i < D; ++i) bx[i] = fmaf(bar[EXP0 + i], th[EXP0 + i], bx[i]);
         }
     }
+
+    // Reverse mode of eval_jvp: adjoints bar (on Theta) and dbar (on dTheta), both consumed,
+    // give bx = dL/dx (includes the second-order term sum_t dbar_t Hess(Theta_t) v) and bv = dL/dv.
+    // th, dth must hold eval_jvp(x, v).
+    static __device__ __forceinline__ void vjp_of_jvp(const float (&x)[D], const float (&v)[D], const float (&th)[P],
+                                                      const float (&dth)[P], float (&bar)[P], float (&dbar)[P],
+                                                      float (&bx)[D], float (&bv)[D]) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            bx[i] = 0.0f;
+            bv[i] = 0.0f;
+        }
+#pragma unroll
+        for (int t = NP - 1; t >= 1; --t) {
+            const int q = tab.parent[t], a = tab.var[t];
+            if (q == 0) {                       // Theta_t = x_a, dTheta_t = v_a
+                bx[a] += bar[t];
+                bv[a] += dbar[t];
+            } else {                            // Theta_t = Theta_q x_a ; dTheta_t = dTheta_q x_a + Theta_q v_a
+                bx[a] = fmaf(bar[t], th[q], fmaf(dbar[t], dth[q], bx[a]));
+                bv[a] = fmaf(dbar[t], th[q], bv[a]);
+                bar[q] = fmaf(bar[t], x[a], fmaf(dbar[t], v[a], bar[q]));
+                dbar[q] = fmaf(dbar[t], x[a], dbar[q]);
+            }
+        }
+        if constexpr (SINE) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const float c = cosf(x[i]), sn = th[SIN0 + i];
+                bx[i] += bar[SIN0 + i] * c - dbar[SIN0 + i] * sn * v[i];
+                bv[i] = fmaf(dbar[SIN0 + i], c, bv[i]);
+            }
+        }
+        if constexpr (EXP) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const float e = th[EXP0 + i];
+                bx[i] += bar[EXP0 + i] * e + dbar[EXP0 + i] * e * v[i];
+                bv[i] = fmaf(dbar[EXP0 + i], e, bv[i]);
+            }
+        }
+    }
 };
 
 }  // namespace symode

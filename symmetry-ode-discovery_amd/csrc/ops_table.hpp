@@ -20,7 +20,8 @@ constexpr LibOps make_ops() {
                   &launch_symreg_reversed<Lib>,
                   &launch_aug_gram<Lib>,
                   &launch_vjp<Lib>,
-                  &launch_forward_jvp<Lib>};
+                  &launch_forward_jvp<Lib>,
+                  &launch_jvp_vjp<Lib>};
 }
 
 #define SYMODE_OPS_ALL_FLAGS(D, O) make_ops<D, O, 0>(), make_ops<D, O, 1>(), make_ops<D, O, 2>(), make_ops<D, O, 3>()

@@ -41,6 +41,8 @@ _SIGNATURES = {
                            c_void_p, c_size_t, c_void_p]),
     "symode_forward_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
+    "symode_jvp_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 ABI_VERSION = 1
@@ -262,6 +264,25 @@ class HipEngine:
                                                 self._ptr(mask), self._ptr(out), self._ptr(jv), self._stream(x)),
                     "symode_forward_jvp")
         return out, jv
+
+
+    def jvp_vjp(self, x, v, g_out, g_jv, xi, mask, order, flags=0):
+        """Reverse mode of forward_jvp: returns (grad_x, grad_v, grad_xi); g_out may be None."""
+        x, v, g_jv = self._dev(x, "x"), self._dev(v, "v"), self._dev(g_jv, "g_jv")
+        g_out = None if g_out is None else self._dev(g_out, "g_out")
+        d = x.shape[-1]
+        n = x.numel() // d
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        p = self._check_coef(xi, mask, d, order, flags)
+        gx, gv = torch.empty_like(x), torch.empty_like(x)
+        gxi = torch.empty(d, p, dtype=torch.float32, device=x.device)
+        ws = self.workspace(x.device, d, order, flags, 1, n)
+        self._check(self.lib.symode_jvp_vjp(self._ptr(x), self._ptr(v), self._ptr(g_out), self._ptr(g_jv), n, d, order,
+                                            flags, self._ptr(xi), self._ptr(mask), self._ptr(gx), self._ptr(gv),
+                                            self._ptr(gxi), self._ptr(ws), ws.numel() * 8, self._stream(x)),
+                    "symode_jvp_vjp")
+        return gx, gv, gxi
 
 
 _ENGINE = None

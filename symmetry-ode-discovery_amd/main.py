@@ -1,0 +1,110 @@
+"""Driver with the reference's main.py flag / config surface for the equation-discovery runs:
+
+    python -m symode_amd.main --seed 0 --config dosc/noise20_sindy.cfg        (from a directory holding run_configs/)
+
+args -> seed -> dataset -> loaders -> autoencoder / generator -> optional LaLiGAN load ->
+regressor (with the equivariance constraint when --eq_constraint) -> train fn -> checkpoints ->
+eval_results/<save_dir>/seed{seed}.npz, as main.py:18-140 of the reference.  Symmetry
+*discovery* (--mt_data, train_lassi) is out of scope and exits with a message.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import train as T
+from .autoencoder import AutoEncoder
+from .dataset import get_dataset
+from .evaluation import eval_sindy_regressor, sindy_truth
+from .lie import LieGenerator
+from .parser_utils import get_args
+from .sindy import SINDyRegression
+
+
+def main(argv=None):
+    args = get_args(argv=argv)
+    T.wandb.init(project='anonym', entity='anonym', name=args.wandb_name, config=args)
+    seed = args.seed
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    args = vars(args)
+    if str(args['device']) == 'cpu':
+        raise SystemExit('symode_amd runs the SINDy path on the GPU only (no CPU fallback): a HIP device is required')
+
+    train_dataset, val_dataset, args = get_dataset(args)
+    if args['sindy_optimizer'] != 'lbfgs':
+        train_loader = DataLoader(train_dataset, batch_size=args['batch_size'], shuffle=True)
+    else:
+        data_size = int(len(train_dataset) * args['lbfgs_subsample'])
+        train_loader = DataLoader(train_dataset, batch_size=data_size, shuffle=True)
+    val_loader = DataLoader(val_dataset, batch_size=args['batch_size'], shuffle=False)
+
+    autoencoder = AutoEncoder(**args).to(args['device'])
+    generator = LieGenerator(**args).to(args['device'])
+
+    laligan_path = args['load_laligan']
+    if laligan_path is not None:
+        autoencoder.load_state_dict(torch.load(f'saved_models/{laligan_path}/autoencoder.pt', weights_only=True))
+        saved = torch.load(f'saved_models/{laligan_path}/generator.pt', weights_only=True)
+        current = generator.state_dict()
+        for name, param in current.items():                       # tolerate older generator files (main.py:52-60)
+            saved.setdefault(name, param)
+        generator.load_state_dict({k: v for k, v in saved.items() if k in current})
+        masks = torch.load(f'saved_models/{laligan_path}/generator_mask.pt', weights_only=True)
+        generator.masks = [m.to(args['device']) if m is not None else None for m in masks]
+    if args['fix_laligan']:
+        for module in (autoencoder, generator):
+            for param in module.parameters():
+                param.requires_grad = False
+
+    if args['eq_constraint']:
+        L_list = generator.get_full_basis_list()
+        repr_dim = L_list[0].shape[-1] // args['n_comps']
+        args['L_list'] = [L[:repr_dim, :repr_dim].detach().cpu() for L in L_list]      # main.py:72-76
+    regressor = SINDyRegression(**args).to(args['device'])
+    if args['distill_latent']:
+        args_distill = dict(args, eq_constraint=False, use_latent=False, L_list=[])
+        regressor_dst = SINDyRegression(**args_distill).to(args['device'])
+    else:
+        regressor_dst = None
+
+    if args['mt_data']:
+        train_fn = T.train_lassi
+    elif args['sindy_optimizer'] == 'lbfgs':
+        train_fn = T.train_SIGED_lbfgs
+    else:
+        train_fn = T.train_SIGED
+    train_fn(autoencoder=autoencoder, discriminator=None, generator=generator, regressor=regressor,
+             regressor_dst=regressor_dst, train_loader=train_loader, test_loader=val_loader, **args)
+
+    out = f'saved_models/{args["save_dir"]}'
+    os.makedirs(out, exist_ok=True)
+    torch.save(autoencoder.state_dict(), f'{out}/autoencoder.pt')
+    torch.save(generator.state_dict(), f'{out}/generator.pt')
+    torch.save(generator.masks, f'{out}/generator_mask.pt')
+    torch.save(regressor.state_dict(), f'{out}/regressor.pt')
+    torch.save(regressor.mask, f'{out}/regressor_mask.pt')             # additive: the reference drops the mask
+    torch.save(regressor.L_list, f'{out}/regressor_lie_list.pt')
+    if regressor_dst is not None:
+        torch.save(regressor_dst.state_dict(), f'{out}/regressor.pt')  # overwrites, as main.py:116-117 does
+
+    print('\n=== Evaluation ===\n')
+    true_eq = sindy_truth[args['task']]
+    regressor_eval = regressor_dst if args['distill_latent'] else regressor
+    coef, cf, mse, cf_all, mse_all = eval_sindy_regressor(regressor_eval, true_eq)
+    print(f'Correct form: {cf}')
+    print(f'MSE: {np.where(cf, mse, 0.0)}')
+    print(f'MSE (any): {mse}')
+    eval_save_dir = f'eval_results/{args["save_dir"]}'
+    os.makedirs(eval_save_dir, exist_ok=True)
+    np.savez(f'{eval_save_dir}/seed{seed}.npz', coefficients=coef, correct_form=cf, mse=mse, correct_form_all=cf_all,
+             mse_all=mse_all)
+    T.wandb.finish()
+    return regressor_eval
+
+
+if __name__ == '__main__':
+    main()

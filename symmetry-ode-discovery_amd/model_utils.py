@@ -1,0 +1,296 @@
+"""Symmetry regularisers and the fixed-step integrator -- surface of the reference's model_utils.py.
+
+``make_*symmreg*`` return callables with the reference's signatures (model_utils.py:214-221);
+``odeint`` keeps its signature (model_utils.py:223-255).  Division of labour:
+
+  * the autoencoder / generator halves are stock PyTorch-ROCm modules (out of scope by
+    north_star) and are only *called* here;
+  * everything that touches the SINDy library runs in HIP kernels: the regressor's forward and
+    vjp (autograd route), its analytic JVP ``(J_Theta(x) v) Xi^T`` (no double-backward trick:
+    SURVEY H3), the fused K-step integrator, and the fully fused reversed regulariser once
+    ``(g(x), J_g(x))`` have been precomputed (they do not depend on Xi: model_utils.py:172-211).
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+from torch.autograd.functional import jvp
+
+from .sindy import SINDyRegression
+
+
+# --------------------------------------------------------------------------------------------
+# odeint                                                            ref: model_utils.py:223-255
+# --------------------------------------------------------------------------------------------
+def odeint(f, x0, t, dt, method='euler', full_traj=False):
+    '''
+    Integrate an ODE f over a time interval differentiably (fixed step).
+    f: nn.Module / callable RHS;  x0: initial state;  t: time;  dt: step;  method: 'euler' | 'rk4'.
+    A SINDyRegression RHS with no gradient requested and no trajectory wanted runs as ONE fused
+    kernel (all K steps in registers); otherwise the steps are chained through autograd.
+    '''
+    n_steps = int(t / dt)
+    if method not in ('euler', 'rk4'):
+        raise ValueError('Unrecognized ODEInt method.')
+    fused = (isinstance(f, SINDyRegression) and not full_traj and x0.is_cuda
+             and not (torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in f.parameters()))))
+    if fused:
+        xi = f.get_Xi().detach()
+        lead = x0.shape[:-1]
+        out = f.engine.odeint(x0.reshape(-1, f.latent_dim), xi, f.mask, f.poly_order, f.flags, n_steps, dt, method)
+        return out.reshape(*lead, f.latent_dim)
+    traj = []
+    for _ in range(n_steps):
+        if method == 'euler':
+            x0 = x0 + dt * f(x0)
+        else:
+            k1 = f(x0)
+            k2 = f(x0 + dt / 2 * k1)
+            k3 = f(x0 + dt / 2 * k2)
+            k4 = f(x0 + dt * k3)
+            x0 = x0 + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        if full_traj:
+            traj.append(x0)
+    return torch.stack(traj, dim=0) if full_traj else x0
+
+
+class _EulerFlow:
+    """f = odeint(regressor, ., int_t, int_dt) together with its tangent map.
+
+    ``tangent(x, v)`` returns ``(f(x), J_f(x) v)`` by propagating the tangent through the same
+    steps with the regressor's analytic JVP -- the quantity the reference obtains from
+    ``jvp(f, x, v, create_graph=True)`` (model_utils.py:56) -- differentiable w.r.t. Xi.
+    """
+
+    def __init__(self, regressor, int_t, int_dt, method='euler'):
+        self.regressor, self.int_t, self.int_dt, self.method = regressor, int_t, int_dt, method
+
+    def __call__(self, x):
+        return odeint(self.regressor, x, self.int_t, self.int_dt, self.method)
+
+    def tangent(self, x, v):
+        n_steps = int(self.int_t / self.int_dt)
+        reg, dt = self.regressor, self.int_dt
+        for _ in range(n_steps):
+            if self.method != 'euler':
+                raise NotImplementedError('tangent flow is implemented for the Euler integrator')
+            h, jv = reg.forward_and_jvp(x, v)
+            x = x + dt * h
+            v = v + dt * jv
+        return x, v
+
+
+def _z_mean(autoencoder, z_mean):
+    return autoencoder.encoder[-2].bias if z_mean is None else z_mean          # model_utils.py:46
+
+
+def _jvp_fn(require_grad):
+    return partial(jvp, create_graph=True, strict=True) if require_grad else jvp
+
+
+# --------------------------------------------------------------------------------------------
+# S2: infinitesimal                                                   ref: model_utils.py:8-67
+# --------------------------------------------------------------------------------------------
+def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global', z_mean=None, relative=True,
+              require_grad=False, numpy=False):
+    if numpy:
+        x_fx = torch.from_numpy(x_fx).float().to(autoencoder.device)
+        if z_mean is not None:
+            z_mean = torch.from_numpy(z_mean).float().to(autoencoder.device)
+        if require_grad:
+            raise ValueError('Cannot require grad when numpy=True.')
+    if f is None and dfdx is None:
+        raise ValueError('Either f or dfdx must be specified.')
+    if f is not None and dfdx is not None:
+        raise ValueError('Only one of f and dfdx can be specified.')
+    jvp_fn = _jvp_fn(require_grad)
+    autoencoder.eval()
+    generator.eval()
+    with torch.set_grad_enabled(require_grad):
+        loss = 0.0
+        z = autoencoder.encode(x_fx)
+        x = x_fx[:, 0]
+        if normalize == 'in_batch':
+            z = z - z.mean(dim=0, keepdim=True)
+        elif normalize == 'global':
+            z = z - _z_mean(autoencoder, z_mean)
+        z_shape = z.shape
+        for v in generator.get_full_basis_list():
+            v_z = torch.einsum('jk,...k->...j', v, z.reshape(z_shape[0], -1)).reshape(z_shape)
+            v_x_fx = jvp_fn(autoencoder.decoder, z, v=v_z)[1]                    # stock PyTorch MLP jvp
+            v_x, v_fx = v_x_fx[:, 0], v_x_fx[:, 1]
+            if f is not None:
+                if isinstance(f, _EulerFlow):
+                    input_variation = f.tangent(x, v_x)[1]                       # HIP analytic tangent flow
+                else:
+                    input_variation = jvp_fn(f, x, v_x)[1]                       # arbitrary f: autograd
+            else:
+                input_variation = torch.einsum('bjk,bk->bj', dfdx, v_x)
+            if not relative:
+                loss += torch.mean((input_variation - v_fx) ** 2)
+            else:
+                loss += torch.mean((input_variation - v_fx) ** 2) / torch.mean(input_variation ** 2)
+    if numpy:
+        loss = loss.cpu().numpy()
+    return loss
+
+
+# --------------------------------------------------------------------------------------------
+# S3: finite                                                         ref: model_utils.py:69-124
+# --------------------------------------------------------------------------------------------
+def symmreg_f(x_fx, autoencoder, generator, f, normalize='global', z_mean=None, relative=True, require_grad=False,
+              numpy=False):
+    autoencoder.eval()
+    generator.eval()
+    if numpy:
+        x_fx = torch.from_numpy(x_fx).float().to(generator.Li[0].device)
+        if z_mean is not None:
+            z_mean = torch.from_numpy(z_mean).float().to(generator.Li[0].device)
+        if require_grad:
+            raise ValueError('Cannot require grad when numpy=True.')
+    with torch.set_grad_enabled(require_grad):
+        loss = 0.0
+        z = autoencoder.encode(x_fx)
+        fx = x_fx[:, 1]
+        if normalize == 'in_batch':
+            zm = z.mean(dim=0, keepdim=True)
+        else:
+            zm = _z_mean(autoencoder, z_mean)
+        z = z - zm
+        z_shape = z.shape
+        for g in generator.get_deterministic_group_elems():
+            g_z = torch.einsum('jk,...k->...j', g, z.reshape(z_shape[0], -1)).reshape(z_shape) + zm
+            g_x_fx = autoencoder.decode(g_z)
+            g_x, g_fx = g_x_fx[:, 0], g_x_fx[:, 1]
+            if numpy:
+                g_x = g_x.cpu().numpy()
+            f_g_x = f(g_x)
+            if numpy:
+                f_g_x = torch.from_numpy(f_g_x).float().to(generator.Li[0].device)
+            if not relative:
+                loss += torch.mean((f_g_x - g_fx) ** 2)
+            else:
+                loss += torch.mean((f_g_x - g_fx) ** 2) / torch.mean((f_g_x - fx) ** 2)
+    if numpy:
+        loss = loss.cpu().numpy()
+    return loss
+
+
+# --------------------------------------------------------------------------------------------
+# S4: reversed                                                      ref: model_utils.py:126-211
+# --------------------------------------------------------------------------------------------
+def _group_transform(x, autoencoder, g, normalize='global', z_mean=None):
+    xx = torch.stack([x, x], dim=1)
+    z = autoencoder.encode(xx)
+    zm = z.mean(dim=0, keepdim=True) if normalize == 'in_batch' else _z_mean(autoencoder, z_mean)
+    z = z - zm
+    z_shape = z.shape
+    g_z = torch.einsum('jk,...k->...j', g, z.reshape(z_shape[0], -1)).reshape(z_shape) + zm
+    return autoencoder.decode(g_z)[:, 0]
+
+
+def precompute_symmreg_r(x, autoencoder, generator, z_mean=None, scale=0.01):
+    '''
+    g(x) and J_g(x) for every deterministic group element -- they do not depend on the ODE, so
+    a frozen autoencoder lets them be computed once per dataset (model_utils.py:172-211).
+    Returns (gx_list, Jgx_list) with Jgx of shape (B, d, d); the reference's vmap version
+    carries a stray singleton axis and transposed per-sample stacking (PySR-only path).
+    '''
+    autoencoder.eval()
+    generator.eval()
+    gx_list, Jgx_list = [], []
+    d = x.shape[-1]
+    with torch.no_grad():
+        for g in generator.get_deterministic_group_elems(scale=scale):
+            tr = partial(_group_transform, autoencoder=autoencoder, g=g, normalize='global', z_mean=z_mean)
+            gx_list.append(tr(x))
+            cols = []
+            for j in range(d):
+                e = torch.zeros_like(x)
+                e[:, j] = 1.0
+                cols.append(jvp(tr, x, v=e)[1])
+            Jgx_list.append(torch.stack(cols, dim=-1))
+    return gx_list, Jgx_list
+
+
+class _ReversedFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xi, mask, x, gx, jgx, reg):
+        loss, grad = reg.engine.symreg_reversed(x, gx, jgx, xi.detach(), mask, reg.poly_order, reg.flags)
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g * grad, None, None, None, None, None
+
+
+_R_CACHE = {}
+
+
+def symmreg_r(x, autoencoder, generator, h, normalize='global', z_mean=None, require_grad=False, scale=0.01):
+    '''
+    Reversed symmetry loss  sum_g mean((J_g(x) h(x) - h(g(x)))^2).
+    With a SINDyRegression ``h`` and a frozen autoencoder, (g(x), J_g(x)) are computed once per
+    (x, autoencoder, generator) and every later call is one fused HIP kernel; any other ``h``
+    takes the reference's autograd route.
+    '''
+    autoencoder.eval()
+    generator.eval()
+    frozen = not any(p.requires_grad for p in list(autoencoder.parameters()) + list(generator.parameters()))
+    if isinstance(h, SINDyRegression) and normalize == 'global' and frozen and x.is_cuda:
+        key = (x.data_ptr(), x._version, tuple(x.shape), id(autoencoder), id(generator), float(scale))
+        if key not in _R_CACHE:
+            _R_CACHE.clear()
+            gx, jgx = precompute_symmreg_r(x, autoencoder, generator, z_mean=z_mean, scale=scale)
+            _R_CACHE[key] = (torch.stack(gx).contiguous(), torch.stack(jgx).contiguous())
+        gx, jgx = _R_CACHE[key]
+        with torch.set_grad_enabled(require_grad):
+            return _ReversedFused.apply(h.get_Xi(), h.mask, x, gx, jgx, h)
+    jvp_fn = _jvp_fn(require_grad)
+    with torch.set_grad_enabled(require_grad):
+        loss = 0.0
+        for g in generator.get_deterministic_group_elems(scale=scale):
+            tr = partial(_group_transform, autoencoder=autoencoder, g=g, normalize=normalize, z_mean=z_mean)
+            gx = tr(x)
+            hx = h(x)
+            variation1 = jvp_fn(tr, x, v=hx)[1]
+            variation2 = h(gx)
+            loss += torch.mean((variation1 - variation2) ** 2)
+    return loss
+
+
+# --------------------------------------------------------------------------------------------
+# S1: linear latent regulariser                                          ref: train.py:502-507
+# --------------------------------------------------------------------------------------------
+class _LinearFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xi, mask, z, L, reg):
+        loss, grad = reg.engine.symreg_linear(z, xi.detach(), mask, L, reg.poly_order, reg.flags)
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g * grad, None, None, None, None
+
+
+def symmreg_linear(z, regressor, basis_list):
+    """sum_v || J_h(z)(v z) - v h(z) ||_F^2 for h = regressor: one fused kernel over all generators.
+    (z is treated as data: the gradient reaches Xi only, as in the latent L-BFGS use.)"""
+    d = regressor.latent_dim
+    L = torch.stack([v[:d, :d] for v in basis_list]).to(z.device).float().contiguous()
+    return _LinearFused.apply(regressor.get_Xi(), regressor.mask, z.detach().reshape(-1, d), L, regressor)
+
+
+make_symmreg = lambda autoencoder, generator: partial(symmreg_i, autoencoder=autoencoder, generator=generator)  # noqa: E731
+make_symmreg_pttrain = lambda autoencoder, generator: partial(symmreg_i, autoencoder=autoencoder, generator=generator, require_grad=True)  # noqa: E731
+make_symmreg_np = lambda autoencoder, generator: partial(symmreg_i, autoencoder=autoencoder, generator=generator, numpy=True)  # noqa: E731
+make_fsymmreg = lambda autoencoder, generator: partial(symmreg_f, autoencoder=autoencoder, generator=generator)  # noqa: E731
+make_fsymmreg_pttrain = lambda autoencoder, generator: partial(symmreg_f, autoencoder=autoencoder, generator=generator, require_grad=True)  # noqa: E731
+make_fsymmreg_np = lambda autoencoder, generator: partial(symmreg_f, autoencoder=autoencoder, generator=generator, numpy=True)  # noqa: E731
+make_rsymmreg = lambda autoencoder, generator: partial(symmreg_r, autoencoder=autoencoder, generator=generator)  # noqa: E731
+make_rsymmreg_pttrain = lambda autoencoder, generator: partial(symmreg_r, autoencoder=autoencoder, generator=generator, require_grad=True)  # noqa: E731

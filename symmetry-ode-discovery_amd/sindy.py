@@ -45,6 +45,26 @@ class _Forward(torch.autograd.Function):
         return gx, (gxi if ctx.needs_input_grad[1] else None), None, None
 
 
+class _ForwardJvp(torch.autograd.Function):
+    """(out, jv) = (Theta(x), J_Theta(x) v) (Xi*mask)^T, differentiable once w.r.t. x, v and Xi."""
+
+    @staticmethod
+    def forward(ctx, x, v, xi, mask, reg):
+        ctx.reg = reg
+        ctx.save_for_backward(x, v, xi, mask)
+        out, jv = reg.engine.forward_jvp(x.detach(), v.detach(), xi.detach(), mask, reg.poly_order, reg.flags)
+        return out, jv
+
+    @staticmethod
+    def backward(ctx, g_out, g_jv):
+        x, v, xi, mask = ctx.saved_tensors
+        reg = ctx.reg
+        g_jv = torch.zeros_like(x) if g_jv is None else g_jv.contiguous()
+        gx, gv, gxi = reg.engine.jvp_vjp(x.detach(), v.detach(), None if g_out is None else g_out.contiguous(), g_jv,
+                                         xi.detach(), mask, reg.poly_order, reg.flags)
+        return gx, gv, gxi, None, None
+
+
 class _FusedMSE(torch.autograd.Function):
     """mean((Theta(x)(Xi*mask)^T - dx)^2) with its Xi-gradient from the same single pass."""
 
@@ -124,6 +144,14 @@ class SINDyRegression(nn.Module):
         """J_regressor(x) . v  =  (J_Theta(x) v) (Xi*mask)^T -- analytic, no double backward."""
         xi = self._coef()
         return self.engine.forward_jvp(x, v, xi.detach(), self.mask, self.poly_order, self.flags)[1]
+
+    def forward_and_jvp(self, x, v):
+        """(regressor(x), J_regressor(x) v), differentiable once w.r.t. x, v and the parameters
+        (HIP forward-mode kernel + its hand-written reverse, second-order term included)."""
+        xi = self._coef()
+        lead = x.shape[:-1]
+        out, jv = _ForwardJvp.apply(x.reshape(-1, self.latent_dim), v.reshape(-1, self.latent_dim), xi, self.mask, self)
+        return out.reshape(*lead, self.latent_dim), jv.reshape(*lead, self.latent_dim)
 
     # ------------------------------------------------------------------ constraint
     def get_M_list(self):
@@ -267,3 +295,66 @@ def solve_SINDy(regressor, x, y, w_sindy_reg, st_threshold, max_iter=5, **kwargs
         if converged:
             break
     return residual
+
+
+class WSINDyWrapper():
+    """
+    Weak SINDy as a regularised least-squares problem (reference sindy.py:327-395): trigonometric
+    test functions g_k(t) = sqrt(2/T) sin(k pi t / T), V = dt g, V' = dt g'; G = V Theta(x), b = -V' x;
+    solve  min || [V^T G; sqrt(gamma) I] w - [V^T b; 0] ||  on the current support, then threshold.
+
+    Theta(x) comes from the HIP library kernel; the (n_test x T)(T x p) contractions are plain
+    library GEMMs (torch/hipBLAS, fp64); the (p x p) normal system is solved on the host with
+    the same LAPACK semantics as solve_SINDy_one_step.
+    """
+
+    def __init__(self, regressor, t, t_max, num_test_funcs=50, test_func_family='trig', device='cuda', **kwargs):
+        self.t = t.to(device)
+        self.dt = self.t[1] - self.t[0]
+        self.regressor = regressor
+        if test_func_family != 'trig':
+            raise NotImplementedError(f'test_func_family={test_func_family} not implemented')
+        k = torch.arange(1, num_test_funcs + 1, dtype=torch.float32, device=device).view(-1, 1)
+        amp = (2 / t_max) ** 0.5
+        g = amp * torch.sin(k * torch.pi * self.t / t_max)
+        g_drv = amp * k * np.pi / t_max * torch.cos(k * np.pi * self.t / t_max)
+        self.V = self.dt * g                                                      # sindy.py:346-347
+        self.V_drv = self.dt * g_drv
+
+    def solve(self, x, w_sindy_reg, st_threshold, **kwargs):
+        reg = self.regressor
+        d = reg.latent_dim
+        with torch.no_grad():
+            theta = reg.eval_Theta_at(x)                                          # HIP
+            V, Vd = self.V.double(), self.V_drv.double()
+            G = V @ theta.double()                                                # (K, p)
+            b = -Vd @ x.double()                                                  # (K, d)
+            A = V.T @ G                                                           # rows of the reference's G_aug
+            rhs = V.T @ b
+            p = G.shape[1]
+            Gn = (A.T @ A + float(w_sindy_reg) * torch.eye(p, dtype=torch.float64, device=A.device)).cpu().numpy()
+            Cn = (A.T @ rhs).cpu().numpy()                                        # (p, d)
+            bb = float((rhs * rhs).sum())
+            m_rows = A.shape[0] + p
+            mask = (reg.mask > 0.0).cpu().numpy()
+            driver = kwargs.get('lstsq_driver', reg.lstsq_driver)
+            prev_mask = reg.mask.clone()
+            if mask.all():
+                W, _ = lstsq_normal(Gn, Cn, m_rows, driver)
+                reg.Xi.data = torch.from_numpy(W.T.copy()).float().to(reg.mask.device)
+                residual = np.mean([Cn[:, j] @ W[:, j] * -2 + W[:, j] @ Gn @ W[:, j] for j in range(d)]) + bb / d
+            else:
+                flat = mask.reshape(-1)
+                Gb = np.zeros((d * p, d * p))
+                for j in range(d):
+                    Gb[j * p:(j + 1) * p, j * p:(j + 1) * p] = Gn
+                cb = Cn.T.reshape(-1)
+                Gm, cm = Gb[flat][:, flat], cb[flat]
+                w, _ = lstsq_normal(Gm, cm, d * m_rows, driver)
+                new_coef = np.zeros((d, p))
+                new_coef[mask] = w
+                reg.Xi.data = torch.from_numpy(new_coef).float().to(reg.mask.device)
+                residual = bb - 2 * w @ cm + w @ Gm @ w
+            reg.set_threshold(st_threshold)
+            converged = torch.allclose(prev_mask, reg.mask)
+        return float(residual), converged

@@ -62,3 +62,41 @@ class TinyAE:
 def projector(Q):
     Q = torch.as_tensor(Q, dtype=torch.float64)
     return Q @ torch.linalg.pinv(Q)
+
+
+def load_fixture_autoencoder(g, prefix, activation, device="cpu"):
+    """Instantiate the product's stock AutoEncoder and fill it with the golden fixture's weights
+    (same module walk order as tools/gen_golden.py::_ae_arrays)."""
+    from symode_amd.autoencoder import AutoEncoder
+    hidden = g[f"{prefix}_enc_W0"].shape[0]
+    n_layers = int(g[f"{prefix}_enc_n"]) - 1
+    ae = AutoEncoder(ae_arch="mlp", input_dim=2, hidden_dim=hidden, latent_dim=2, n_layers=n_layers, n_comps=2,
+                     activation=activation, activation_args=[], batch_norm=True, ortho_ae=False)
+    with torch.no_grad():
+        for tag, seq in (("enc", ae.encoder), ("dec", ae.decoder)):
+            k = 0
+            for m in seq.modules():
+                if isinstance(m, torch.nn.Linear):
+                    m.weight.copy_(t(g[f"{prefix}_{tag}_W{k}"]))
+                    m.bias.copy_(t(g[f"{prefix}_{tag}_b{k}"]))
+                    k += 1
+                elif isinstance(m, torch.nn.BatchNorm1d):
+                    j = k - 1
+                    m.weight.copy_(t(g[f"{prefix}_{tag}_bnw{j}"]))
+                    m.bias.copy_(t(g[f"{prefix}_{tag}_bnb{j}"]))
+                    m.running_mean.copy_(t(g[f"{prefix}_{tag}_bnm{j}"]))
+                    m.running_var.copy_(t(g[f"{prefix}_{tag}_bnv{j}"]))
+    for p in ae.parameters():
+        p.requires_grad = False
+    return ae.to(device).eval()
+
+
+def load_fixture_generator(g, prefix, repr_str, device="cpu"):
+    from symode_amd.lie import LieGenerator
+    gen = LieGenerator(repr=repr_str, group_idx="0", sigma_init=1, gan_st_thres=0.3, keep_center=True, device=device)
+    with torch.no_grad():
+        gen.Li[0].copy_(t(g[f"{prefix}_Li"]))
+        gen.sigma[0].copy_(t(g[f"{prefix}_sigma"]))
+    for p in gen.parameters():
+        p.requires_grad = False
+    return gen.to(device).eval()

@@ -31,10 +31,11 @@ class OracleEngine:
 
     def vjp(self, x, g, xi, mask, order, flags=0, need_grad_x=True):
         m = torch.ones_like(xi) if mask is None else mask
-        xx = x.detach().clone().requires_grad_(True)
-        w = xi.detach().clone().requires_grad_(True)
-        out = O.forward(xx, w, m, order, *_fl(flags))
-        gx, gw = torch.autograd.grad(out, (xx, w), g)
+        with torch.enable_grad():
+            xx = x.detach().clone().requires_grad_(True)
+            w = xi.detach().clone().requires_grad_(True)
+            out = O.forward(xx, w, m, order, *_fl(flags))
+            gx, gw = torch.autograd.grad(out, (xx, w), g)
         return (gx if need_grad_x else None), gw
 
     def odeint(self, x, xi, mask, order, flags, n_steps, dt, method="euler"):
@@ -50,7 +51,8 @@ class OracleEngine:
         M = torch.ones_like(XI) if mask is None else mask.reshape(S, d, -1)
         losses, grads = [], []
         for s in range(S):
-            l, g = O.mse_loss_and_grad(X[s], DX[s], XI[s], M[s], order, *_fl(flags))
+            with torch.enable_grad():          # callers sit inside autograd.Function.forward (grad mode off)
+                l, g = O.mse_loss_and_grad(X[s], DX[s], XI[s], M[s], order, *_fl(flags))
             scale = 1.0 if inv_count is None else inv_count * n * d
             losses.append(l * scale)
             grads.append(g * scale)
@@ -71,14 +73,16 @@ class OracleEngine:
         d = z.shape[-1]
         reg = O.OracleRegressor(d, order, *_fl(flags), Xi0=xi)
         reg.mask = torch.ones_like(xi) if mask is None else mask
-        loss = O.symreg_linear_latent(z, list(L.reshape(-1, d, d)), reg)
-        loss.backward()
+        with torch.enable_grad():
+            loss = O.symreg_linear_latent(z, list(L.reshape(-1, d, d)), reg)
+            loss.backward()
         return loss.detach(), reg.Xi.grad
 
     def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0):
         d = x.shape[-1]
         reg = O.OracleRegressor(d, order, *_fl(flags), Xi0=xi)
         reg.mask = torch.ones_like(xi) if mask is None else mask
-        loss = O.symreg_reversed_precomputed(x, list(gx), list(jgx), reg)
-        loss.backward()
+        with torch.enable_grad():
+            loss = O.symreg_reversed_precomputed(x, list(gx), list(jgx), reg)
+            loss.backward()
         return loss.detach(), reg.Xi.grad

@@ -1,0 +1,138 @@
+"""GPU parity of the training-loop layer: L-BFGS trainer, symmetry regularisers (S1-S4) and the
+integrator, through the HIP engine, against the reference's recorded outputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sindy_oracle as O
+from tests.helpers import load_fixture_autoencoder, load_fixture_generator, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def S():
+    import symode_amd
+    assert torch.cuda.is_available()
+    return symode_amd
+
+
+def _regressor(S, g, tag, d, order, thr):
+    if f"{tag}_init_Xi" in g.files:
+        r = S.SINDyRegression(d, order, False, False, threshold=thr, device=DEV)
+        r.Xi.data = t(g[f"{tag}_init_Xi"]).to(DEV)
+    else:
+        r = S.SINDyRegression(d, order, False, False, L_list=[torch.tensor([[0.0, 1.0], [-1.0, 0.0]])], threshold=thr,
+                              device=DEV, constrain_constant=False)
+        r.Q = t(g[f"{tag}_Q"]).to(DEV)
+        r.beta.data, r.const.data = t(g[f"{tag}_init_beta"]).to(DEV), t(g[f"{tag}_init_const"]).to(DEV)
+    return r
+
+
+@pytest.mark.parametrize("tag", ["dosc_sindy", "dosc_esindy", "selkov_sindy"])
+def test_lbfgs_trainer_on_gpu_matches_reference_run(S, golden, tag, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    g = golden("f4_lbfgs")
+    d, order = [int(v) for v in g[f"{tag}_cfg"]]
+    lr, st_freq, thr, epochs = g[f"{tag}_hp"]
+    x, dx = t(g[f"{tag}_x"]), t(g[f"{tag}_dx"])
+    r = _regressor(S, g, tag, d, order, float(thr))
+    ident = torch.nn.Identity()
+    S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], test_loader=[], num_epochs=int(epochs), device=DEV,
+                              log_interval=10 ** 9, save_interval=10 ** 9, save_dir="t", autoencoder=ident, generator=ident,
+                              regressor=r, regressor_dst=None, use_latent=False, distill_latent=False, lr_sindy=float(lr),
+                              w_sindy_z=0.0, w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="i",
+                              w_sym_reg=0.0, st_freq=int(st_freq), threshold=float(thr), int_t=0.1, int_dt=0.01, print_eq=False)
+    assert np.array_equal(r.mask.cpu().numpy(), g[f"{tag}_mask_final"])            # identical sparsity mask
+    want = g[f"{tag}_Xi_final"]
+    got = r.get_Xi().detach().cpu().numpy()
+    # the iteration ends on "parameter update < 1e-3" (train.py:643): both runs sit within that ball of the minimiser
+    assert np.allclose(got * g[f"{tag}_mask_final"], want * g[f"{tag}_mask_final"], rtol=1e-3, atol=1e-4), np.abs(got - want).max()
+    if f"{tag}_eval_cf" in g.files:
+        coef, cf, mse, cf_all, mse_all = S.evaluation.eval_sindy_regressor(r, S.evaluation.sindy_truth[tag.split("_")[0]])
+        assert np.array_equal(cf, g[f"{tag}_eval_cf"]) and bool(cf_all) == bool(g[f"{tag}_eval_cf_all"])
+
+
+@pytest.mark.parametrize("tag,act,rep", [("relu_sim2", "ReLU", "(2,sim2)"), ("tanh_learn", "Tanh", "(2,1,2)")])
+def test_symmetry_regularisers_match_reference(S, golden, tag, act, rep):
+    from symode_amd import model_utils as MU
+    g = golden("f6_symreg")
+    ae = load_fixture_autoencoder(g, tag, act, DEV)
+    gen = load_fixture_generator(g, tag, rep, DEV)
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    r = S.SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.1, device=DEV)
+    r.Xi.data = t(g[f"{tag}_Xi"]).to(DEV)
+    r.mask = t(g[f"{tag}_mask"]).to(DEV)
+    x = t(g[f"{tag}_x"]).to(DEV)
+    K, dt = int(g[f"{tag}_K"]), float(g[f"{tag}_dt"])
+    flow = MU._EulerFlow(r, K * dt + 1e-9, dt)
+
+    # integrator: fused kernel (no grad) and autograd-chained route agree with the reference
+    with torch.no_grad():
+        assert np.allclose(flow(x).cpu().numpy(), g[f"{tag}_euler"], rtol=1e-5, atol=1e-6)
+        assert np.allclose(MU.odeint(r, x, K * dt + 1e-9, dt, full_traj=True).cpu().numpy(), g[f"{tag}_euler_traj"], rtol=1e-5, atol=1e-6)
+        assert np.allclose(MU.odeint(r, x, K * dt + 1e-9, dt, method="rk4").cpu().numpy(), g[f"{tag}_rk4"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(flow(x).detach().cpu().numpy(), g[f"{tag}_euler"], rtol=1e-5, atol=1e-6)     # grad-enabled route
+
+    def run(fn):
+        r.Xi.grad = None
+        loss = fn()
+        loss.backward()
+        return loss.item(), r.Xi.grad.detach().cpu().numpy()
+
+    def check(name, loss, grad, rl=2e-4, rg=2e-3):
+        wl, wg = float(g[f"{tag}_{name}_loss"]), g[f"{tag}_{name}_grad"]
+        assert np.isclose(loss, wl, rtol=rl), (name, loss, wl)
+        assert np.abs(grad - wg).max() <= rg * np.abs(wg).max(), (name, np.abs(grad - wg).max() / np.abs(wg).max())
+
+    s2 = MU.make_symmreg_pttrain(ae, gen)
+    check("s2", *run(lambda: s2(torch.stack([x, flow(x)], dim=1), f=flow)))
+    check("s2abs", *run(lambda: s2(torch.stack([x, flow(x)], dim=1), f=flow, relative=False)))
+    s3 = MU.make_fsymmreg_pttrain(ae, gen)
+    check("s3", *run(lambda: s3(torch.stack([x, flow(x)], dim=1), f=flow)))
+    s4 = MU.make_rsymmreg_pttrain(ae, gen)
+    check("s4", *run(lambda: s4(x, h=r)), rl=1e-3, rg=5e-3)                  # fused kernel on precomputed (g(x), J_g)
+    basis = gen.get_full_basis_list()
+    check("s1", *run(lambda: MU.symmreg_linear(x, r, basis)), rl=1e-4, rg=1e-3)
+
+
+def test_forward_and_jvp_gradients_vs_fp64_double_backward(S):
+    """The hand-written reverse of the forward-mode kernel (second-order term included) against
+    torch's create_graph=True jvp on the fp64 oracle."""
+    torch.manual_seed(2)
+    for d, order, sine, exp in [(2, 3, False, False), (2, 5, False, False), (3, 2, True, True), (1, 4, False, True)]:
+        r = S.SINDyRegression(d, order, sine, exp, threshold=0.1, device=DEV)
+        r.mask = (torch.rand_like(r.mask) > 0.2).float()
+        x, v = torch.randn(300, d) * 0.6, torch.randn(300, d)
+        c1, c2 = torch.randn(300, d), torch.randn(300, d)
+        xg, vg = x.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+        out, jv = r.forward_and_jvp(xg, vg)
+        ((out * c1.to(DEV)).sum() + (jv * c2.to(DEV)).sum()).backward()
+        Xi = r.Xi.detach().cpu().double().requires_grad_(True)
+        xo, vo = x.double().requires_grad_(True), v.double().requires_grad_(True)
+        f = lambda a: O.forward(a, Xi, r.mask.cpu().double(), order, sine, exp)  # noqa: E731
+        oo, jo = torch.autograd.functional.jvp(f, xo, vo, create_graph=True)
+        ((oo * c1.double()).sum() + (jo * c2.double()).sum()).backward()
+        for got, want, nm in [(xg.grad, xo.grad, "x"), (vg.grad, vo.grad, "v"), (r.Xi.grad, Xi.grad, "Xi")]:
+            err = (got.cpu().double() - want).abs().max().item() / want.abs().max().item()
+            assert err < 2e-5, (d, order, nm, err)
+
+
+def test_train_sindy_and_wsindy_on_gpu(S, golden):
+    g = golden("f3_stlsq")
+    x, dx = t(g["selkov_ridge_x"]), t(g["selkov_ridge_dx"])
+    r = S.SINDyRegression(2, 3, False, False, threshold=0.075, device=DEV)
+    S.train.train_SINDy(r, x, dx, num_epochs=8, device=DEV, log_interval=100, save_interval=100, save_dir="t", w_sindy_reg=0.1, threshold=0.075)
+    assert np.array_equal(r.mask.cpu().numpy(), g["selkov_ridge_masks"][-1])
+    w = golden("f7_wsindy")
+    xw = t(w["x"]).to(DEV)
+    n = xw.shape[0]
+    r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV)
+    wr = S.WSINDyWrapper(r, torch.arange(n) * 0.02, float(w["tmax"]), device=DEV)
+    assert np.allclose(wr.V[:, :48].cpu().numpy(), w["V_head"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(wr.V_drv[:, :48].cpu().numpy(), w["V_drv_head"], rtol=1e-5, atol=1e-7)
+    for wm, wx, wc in zip(w["masks"], w["xis"], w["conv"]):
+        res, c = wr.solve(xw, 0.0, 0.05)
+        assert np.array_equal(r.mask.cpu().numpy(), wm) and bool(c) == bool(wc)
+        assert np.allclose(r.Xi.detach().cpu().numpy(), wx, rtol=1e-3, atol=1e-3 * np.abs(wx).max())
