@@ -69,8 +69,11 @@ class BatchedClosure:
             n = b - a
             loss = buf[:n]
             grad = buf[n:].view(n, self.d, self.p)
-            self.engine.loss_grad(self.x[a:b], self.dx[a:b], Xi[a:b], None if mask is None else mask[a:b], self.order,
-                                  self.flags, inv_count=self.inv_count, out=(loss, grad))
+            l, g = self.engine.loss_grad(self.x[a:b], self.dx[a:b], Xi[a:b], None if mask is None else mask[a:b],
+                                         self.order, self.flags, inv_count=self.inv_count, out=(loss, grad))
+            if l.data_ptr() != loss.data_ptr():          # an engine that does not write in place
+                loss.copy_(l)
+                grad.copy_(g)
             if self.distributed:
                 works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
@@ -80,7 +83,7 @@ class BatchedClosure:
         return loss, grad
 
     def evaluate(self, beta, const=None, mask=None):
-        """Closure of all S problems: (loss (S,), d/dbeta, d/dconst)."""
+        """Closure of all S problems: (loss (S,), d/dbeta [or d/dXi when unconstrained], d/dconst)."""
         Xi = self.xi_from(beta, const)
         loss, grad = self.loss_grad_xi(Xi, mask)
         g_beta, g_const = self.grads_to(grad)

@@ -1,0 +1,90 @@
+"""N > 1 path on CPU: two gloo ranks, each holding half of every problem's points; the packed
+[loss | grad] (and Gram) all-reduce must reproduce the single-process full-batch result."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import sindy_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_chunks, constrained, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import symode_amd  # noqa: F401
+    from symode_amd.batched import BatchedClosure
+    from symode_amd.constraint import constraint_Q
+    from tests.oracle_engine import OracleEngine
+    g = torch.Generator().manual_seed(0)
+    S, n, d, order = 5, 600, 2, 3
+    x, dx = torch.randn(S, n, d, generator=g) * 0.7, torch.randn(S, n, d, generator=g)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    Q = None
+    if constrained:
+        Q, uk = constraint_Q([torch.tensor([[0.0, 1.0], [-1.0, 0.0]])], d, order)
+    clos = BatchedClosure(x[:, lo:hi].contiguous(), dx[:, lo:hi].contiguous(), order, Q=Q, use_kron_product=True,
+                          allow_constant=True, group=dist.group.WORLD, n_chunks=n_chunks, engine=OracleEngine())
+    if constrained:
+        beta, const = torch.randn(S, Q.shape[1], generator=g), torch.randn(S, d, 1, generator=g)
+        loss, gb, gc = clos.evaluate(beta, const)
+        res = dict(loss=loss.numpy(), gb=gb.numpy(), gc=gc.numpy())
+    else:
+        Xi = torch.randn(S, d, 10, generator=g)
+        mask = (torch.rand(S, d, 10, generator=g) > 0.3).float()
+        loss, grad, _ = clos.evaluate(Xi, mask=mask)
+        res = dict(loss=loss.numpy(), grad=grad.numpy(), gram=clos.aug_gram().numpy())
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, n_chunks, constrained):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_chunks, constrained, str(tmp_path)), nprocs=2, join=True)
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+
+
+def test_point_sharded_closure_matches_full_batch(tmp_path):
+    r0, r1 = _run(tmp_path, n_chunks=2, constrained=False)
+    g = torch.Generator().manual_seed(0)
+    S, n, d, order = 5, 600, 2, 3
+    x, dx = torch.randn(S, n, d, generator=g) * 0.7, torch.randn(S, n, d, generator=g)
+    Xi = torch.randn(S, d, 10, generator=g)
+    mask = (torch.rand(S, d, 10, generator=g) > 0.3).float()
+    for k in ("loss", "grad", "gram"):
+        assert np.array_equal(r0[k], r1[k])                          # every rank ends with the same sums
+    for s in range(S):
+        wl, wg = O.mse_loss_and_grad(x[s], dx[s], Xi[s], mask[s], order)
+        assert np.isclose(r0["loss"][s], wl.item(), rtol=1e-5)
+        assert np.allclose(r0["grad"][s], wg.numpy(), rtol=1e-4, atol=1e-6)
+        A = torch.cat([O.theta(x[s], order), dx[s]], 1).double()
+        assert np.allclose(r0["gram"][s], (A.T @ A).numpy(), rtol=1e-12)
+
+
+def test_sharded_constrained_closure_gradients(tmp_path):
+    r0, r1 = _run(tmp_path, n_chunks=1, constrained=True)
+    assert np.array_equal(r0["gb"], r1["gb"])
+    from symode_amd.constraint import constraint_Q
+    g = torch.Generator().manual_seed(0)
+    S, n, d, order = 5, 600, 2, 3
+    x, dx = torch.randn(S, n, d, generator=g) * 0.7, torch.randn(S, n, d, generator=g)
+    Q, _ = constraint_Q([torch.tensor([[0.0, 1.0], [-1.0, 0.0]])], d, order)
+    beta, const = torch.randn(S, Q.shape[1], generator=g), torch.randn(S, d, 1, generator=g)
+    for s in range(S):
+        reg = O.OracleRegressor(d, order, L_list=[torch.tensor([[0.0, 1.0], [-1.0, 0.0]])], beta0=beta[s], const0=const[s])
+        reg.Q = Q
+        loss = torch.nn.functional.mse_loss(reg(x[s]), dx[s])
+        loss.backward()
+        assert np.isclose(r0["loss"][s], loss.item(), rtol=1e-5)
+        assert np.allclose(r0["gb"][s], reg.beta.grad.numpy(), rtol=1e-4, atol=1e-6)
+        assert np.allclose(r0["gc"][s], reg.const.grad.numpy(), rtol=1e-4, atol=1e-6)
