@@ -231,6 +231,30 @@ class OracleRegressor:
 # --------------------------------------------------------------------------------------
 
 
+class _LstsqResult:
+    def __init__(self, solution, residuals, rank):
+        self.solution, self.residuals, self.rank = solution, residuals, rank
+
+
+def lstsq_cpu(A: torch.Tensor, B: torch.Tensor) -> _LstsqResult:
+    """``torch.linalg.lstsq(A, B)`` as the reference's CPU path defines it (sindy.py:288):
+    LAPACK ?gelsy with torch's default ``rcond = eps(dtype) * max(m, n)``, empty ``residuals``.
+
+    The LAPACK routine is reached through scipy instead of torch because torch 2.10's CPU wrapper
+    is not reproducible on ill-conditioned systems (identical calls return different ranks --
+    measured in the build container); scipy initialises the pivot array, so
+    this is what the reference computes whenever its own call behaves.
+    """
+    import scipy.linalg as sl
+    a = A.detach().numpy()
+    b = B.detach().numpy()
+    rcond = float(np.finfo(a.dtype).eps) * max(a.shape)
+    if a.shape[1] == 0:
+        return _LstsqResult(torch.zeros((0,) + tuple(b.shape[1:]), dtype=A.dtype), torch.empty(0, dtype=A.dtype), 0)
+    sol, _, rank, _ = sl.lstsq(a, b, cond=rcond, lapack_driver="gelsy", check_finite=False)
+    return _LstsqResult(torch.from_numpy(np.ascontiguousarray(sol)).to(A.dtype), torch.empty(0, dtype=A.dtype), rank)
+
+
 def stlsq_one_step(reg: OracleRegressor, x, y, w_sindy_reg, st_threshold):
     """One ridge-augmented least-squares solve + hard threshold.   ref: sindy.py:250-315
 
@@ -256,7 +280,7 @@ def stlsq_one_step(reg: OracleRegressor, x, y, w_sindy_reg, st_threshold):
             A = A @ Q[mask.flatten()]                                                    # :282
             effective = torch.any(A != 0.0, dim=0)                                       # :284
             A = A[:, effective]
-    lm = torch.linalg.lstsq(A, B)                                                        # :288
+    lm = lstsq_cpu(A, B)                                                                 # :288
     sol = lm.solution
     prev_mask = reg.mask.clone()
     with torch.no_grad():
