@@ -82,6 +82,14 @@ int symode_odeint(const float* x, long n, int d, int order, int flags, const flo
 int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, int d, int order, int flags,
                     double* gram_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same, for n_problems index subsets of ONE shared data set: problem s uses the m points
+ * x[idx[s*m + i]], i < m (int32 row indices < n_src; the caller guarantees the range).
+ * replaces: the per-seed DataLoader subsample (main.py:36-38) of a seed sweep
+ * (run_scripts/*.sh: `for i in {0..49}`) followed by sindy.py:261-288, for all seeds at once. */
+int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const int* idx, long n_problems, long m, int d,
+                           int order, int flags, double* gram_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* S1, linear-latent symmetry regulariser (train.py:502-507 with the intended [1]):
  *   loss = sum_v sum_n || Xi_m J_Theta(z_n)(L_v z_n) - L_v Xi_m Theta(z_n) ||^2,
  *   grad (d, p) = dloss/dxi (masked).  L: (n_gen, d, d). */

@@ -7,7 +7,7 @@ root-level shim ``symode_amd.py`` is on the path, simply ``import symode_amd``.
 import sys as _sys
 
 from . import (autoencoder, batched, constraint, data, dataset, engine, evaluation, library, lie, lstsq, model_utils,  # noqa: F401
-               parser_utils, sindy, train)
+               parser_utils, sindy, sweep, train)
 from .engine import FLAG_EXP, FLAG_SINE, HipEngine, SymodeError, get_engine, library_flags  # noqa: F401
 
 from .sindy import SINDyRegression, WSINDyWrapper, solve_SINDy, solve_SINDy_one_step  # noqa: F401

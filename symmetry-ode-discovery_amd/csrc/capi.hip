@@ -127,7 +127,19 @@ int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, in
     if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
     const int gx = grid_x_for(n, n_problems, 1);
-    return (int)ops->aug_gram(x, dx, n_problems, n, gram_out, (double*)workspace, gx, (hipStream_t)stream);
+    return (int)ops->aug_gram(x, dx, n_problems, n, nullptr, gram_out, (double*)workspace, gx, (hipStream_t)stream);
+}
+
+int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const int* idx, long n_problems, long m, int d,
+                           int order, int flags, double* gram_out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    SYMODE_GET_OPS();
+    if (n_problems < 1 || n_problems > 65535 || m < 1 || n_src < 1 || n_src > 2147483647L) return SYMODE_E_BADSIZE;
+    if (!x || !dx || !idx || !gram_out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(idx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(n_problems, m);
+    const int gx = grid_x_for(m, n_problems, 1);
+    return (int)ops->aug_gram(x, dx, n_problems, m, idx, gram_out, (double*)workspace, gx, (hipStream_t)stream);
 }
 
 int symode_symreg_linear(const float* z, long n, int d, int order, int flags, const float* xi, const float* mask,

@@ -36,15 +36,20 @@ struct GramShape {
 
 template <class Lib>
 __global__ __launch_bounds__(BLOCK) void aug_gram_kernel(const float* __restrict__ x, const float* __restrict__ dx,
-                                                         long N, double* __restrict__ ws) {
+                                                         long N, const int* __restrict__ idx,
+                                                         double* __restrict__ ws) {
     using G = GramShape<Lib>;
     constexpr int D = Lib::D, P = Lib::P, F = G::F, T = G::T, PS = G::PS;
     __shared__ float lds[(BLOCK / WAVE) * G::LDS_PER_WAVE];
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     float* my = lds + wave * G::LDS_PER_WAVE;
     const long s = blockIdx.y;
-    const float* xs = x + s * N * D;
-    const float* ys = dx + s * N * D;
+    // idx == nullptr: problem s owns rows [s*N, (s+1)*N) of x / dx.
+    // idx != nullptr: every problem draws its N points from ONE shared (x, dx) through its row of the
+    // index table (seed sweeps over random subsamples of the same data set, run_scripts/*.sh seed loops).
+    const float* xs = idx ? x : x + s * N * D;
+    const float* ys = idx ? dx : dx + s * N * D;
+    const int* is = idx ? idx + s * N : nullptr;
 
     // zero the padding rows once (features F..FT-1 stay zero for the whole kernel)
     for (int f = F; f < G::FT; ++f) my[f * PS + lane] = 0.0f;
@@ -60,8 +65,9 @@ __global__ __launch_bounds__(BLOCK) void aug_gram_kernel(const float* __restrict
         float feat[F];
         if (n < N) {
             float xp[D], yp[D], th[P];
-            load_point<D>(xs, n, xp);
-            load_point<D>(ys, n, yp);
+            const long src = is ? (long)is[n] : n;
+            load_point<D>(xs, src, xp);
+            load_point<D>(ys, src, yp);
             Lib::eval(xp, th);
 #pragma unroll
             for (int k = 0; k < P; ++k) feat[k] = th[k];
@@ -127,9 +133,9 @@ __global__ __launch_bounds__(BLOCK) void gram_finalize_kernel(const double* __re
 }
 
 template <class Lib>
-hipError_t launch_aug_gram(const float* x, const float* dx, long S, long n, double* gram, double* ws, int gx,
-                           hipStream_t st) {
-    aug_gram_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, ws);
+hipError_t launch_aug_gram(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
+                           int gx, hipStream_t st) {
+    aug_gram_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, idx, ws);
     SYMODE_LAUNCH_CHECK();
     gram_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx * (BLOCK / WAVE), gram);
     SYMODE_LAUNCH_CHECK();

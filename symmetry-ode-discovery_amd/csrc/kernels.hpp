@@ -27,8 +27,8 @@ struct LibOps {
                                 float* loss, float* grad, double* ws, int gx, hipStream_t st);
     hipError_t (*symreg_reversed)(const float* x, const float* gx_, const float* jgx, int n_g, long n, const float* xi,
                                   const float* mask, float* loss, float* grad, double* ws, int gx, hipStream_t st);
-    hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, double* gram, double* ws, int gx,
-                           hipStream_t st);
+    hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
+                           int gx, hipStream_t st);
     hipError_t (*vjp)(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
                       float* grad_xi, double* ws, int gx, hipStream_t st);
     hipError_t (*forward_jvp)(const float* x, const float* v, long n, const float* xi, const float* mask, float* out,

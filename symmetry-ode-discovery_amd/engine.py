@@ -33,6 +33,8 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_aug_gram": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                 c_void_p]),
+    "symode_aug_gram_gather": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
     "symode_symreg_linear": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_symreg_reversed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_void_p,
@@ -200,6 +202,22 @@ class HipEngine:
         self._check(self.lib.symode_aug_gram(self._ptr(x), self._ptr(dx), S, n, d, order, flags, self._ptr(gram),
                                              self._ptr(ws), ws.numel() * 8, self._stream(x)), "symode_aug_gram")
         return gram if batched else gram[0]
+
+    def aug_gram_gather(self, x, dx, idx, order, flags=0):
+        """Gram matrices of S index subsets of one shared data set: x, dx (N, d); idx (S, M) int32 rows."""
+        x, dx = self._dev(x, "x"), self._dev(dx, "dx")
+        idx = self._dev(idx, "idx", torch.int32)
+        if x.dim() != 2 or x.shape != dx.shape or idx.dim() != 2:
+            raise SymodeError("aug_gram_gather expects x, dx (N, d) and idx (S, M)")
+        n_src, d = x.shape
+        S, m = idx.shape
+        p = self.lib_size(d, order, flags)
+        gram = torch.empty(S, p + d, p + d, dtype=torch.float64, device=x.device)
+        ws = self.workspace(x.device, d, order, flags, S, m)
+        self._check(self.lib.symode_aug_gram_gather(self._ptr(x), self._ptr(dx), n_src, self._ptr(idx), S, m, d, order, flags,
+                                                    self._ptr(gram), self._ptr(ws), ws.numel() * 8, self._stream(x)),
+                    "symode_aug_gram_gather")
+        return gram
 
     def symreg_linear(self, z, xi, mask, L, order, flags=0):
         z = self._dev(z, "z")

@@ -222,6 +222,34 @@ def _normal_system(regressor, G, gamma):
     return Gtt, Gty, yy, d, p
 
 
+def stlsq_solve_from_gram(G, N, mask, gamma, d, driver="gelsy"):
+    """Unconstrained ridge least squares on the support ``mask`` (d, p) from the augmented Gram G.
+
+    Returns (Xi (d, p) float64, residual).  Full mask: one (p, p) system with d right-hand sides
+    (sindy.py:288, 300); otherwise the reference's block-diagonal, column-selected system in
+    equation-major order (sindy.py:270-274, 296-298) -- solved as ONE system because gelsy's
+    rank decision is taken over all equations jointly.
+    """
+    p = G.shape[0] - d
+    Gtt = G[:p, :p] + (gamma * gamma) * np.eye(p)
+    Gty = G[:p, p:]
+    yy = np.trace(G[p:, p:])
+    if mask.all():
+        W, _ = lstsq_normal(Gtt, Gty, N + p, driver)
+        res = np.mean([G[p + j, p + j] - 2 * W[:, j] @ Gty[:, j] + W[:, j] @ Gtt @ W[:, j] for j in range(d)])
+        return W.T.copy(), res
+    flat = mask.reshape(-1)
+    Gb = np.zeros((d * p, d * p))
+    for j in range(d):
+        Gb[j * p:(j + 1) * p, j * p:(j + 1) * p] = Gtt
+    cb = Gty.T.reshape(-1)
+    Gm, cm = Gb[flat][:, flat], cb[flat]
+    w, _ = lstsq_normal(Gm, cm, d * (N + p), driver)
+    Xi = np.zeros((d, p))
+    Xi[mask] = w
+    return Xi, yy - 2 * w @ cm + w @ Gm @ w
+
+
 def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
     '''
     Solve  argmin_w ||y - w Theta(x)||^2 + w_sindy_reg^2 ||w||^2  on the current support, then

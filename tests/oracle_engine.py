@@ -69,6 +69,9 @@ class OracleEngine:
         G = torch.stack(out)
         return G if batched else G[0]
 
+    def aug_gram_gather(self, x, dx, idx, order, flags=0):
+        return torch.stack([self.aug_gram(x[i.long()], dx[i.long()], order, flags) for i in idx])
+
     def symreg_linear(self, z, xi, mask, L, order, flags=0):
         d = z.shape[-1]
         reg = O.OracleRegressor(d, order, *_fl(flags), Xi0=xi)

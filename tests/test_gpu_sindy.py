@@ -122,3 +122,25 @@ def test_eval_theta_and_leading_dims(S):
     assert r(x.cuda()).shape == (5, 7, 2)
     with pytest.raises(S.SymodeError):
         r(x)            # CPU input: no fallback
+
+
+def test_gather_gram_and_seed_sweep_on_gpu(S, golden):
+    """64-seed sweep (BASELINE config 4 shape, reduced): one gather launch + host solves vs the oracle per seed."""
+    from symode_amd.sweep import SeedSweepSTLSQ
+    g = golden("f3_stlsq")
+    x, dx = t(g["selkov_ridge_x"]), t(g["selkov_ridge_dx"])
+    sw = SeedSweepSTLSQ(x.cuda(), dx.cuda(), 3, n_seeds=64, subsample=0.5, seed0=0)
+    G = sw.grams()
+    for s in (0, 17, 63):
+        rows = sw.idx[s].long().cpu()
+        A = torch.cat([O.theta(x[rows], 3), dx[rows]], 1).double()
+        assert np.allclose(G[s], (A.T @ A).numpy(), rtol=1e-12, atol=0)
+    Xi, mask, passes = sw.solve(0.1, 0.075)
+    for s in (0, 5, 17, 40, 63):
+        rows = sw.idx[s].long().cpu()
+        reg = O.OracleRegressor(2, 3, threshold=0.075, Xi0=torch.zeros(2, 10))
+        hist = O.stlsq_until_converged(reg, x[rows], dx[rows], 10, 0.1, 0.075)
+        assert np.array_equal(mask[s].numpy(), reg.mask.numpy()), s          # identical sparsity mask per seed
+        assert len(hist) == passes[s]
+        want = reg.Xi.detach().numpy()
+        assert np.allclose(Xi[s].numpy(), want, rtol=1e-5, atol=2e-5 * np.abs(want).max())

@@ -193,3 +193,22 @@ def test_rank_deficient_constrained_system_follows_lapack_semantics(golden):
             assert np.allclose(W, out[1:], rtol=1e-3, atol=1e-4)
         else:   # the irreproducible rank-1 outcome: same collinear part, 4th coefficient lost
             assert np.allclose(W[:3], out[1:4], rtol=1e-3, atol=1e-4) and abs(out[4]) < 1e-5
+
+
+def test_seed_sweep_matches_per_seed_stlsq(golden):
+    """Batched seed sweep (Gram gather + host solves) == running solve_SINDy-style passes seed by seed."""
+    from symode_amd.sweep import SeedSweepSTLSQ
+    g = golden("f3_stlsq")
+    x, dx = t(g["dosc_noisy_x"]), t(g["dosc_noisy_dx"])
+    sw = SeedSweepSTLSQ(x, dx, 3, n_seeds=5, subsample=0.5, seed0=3, engine=OracleEngine())
+    Xi, mask, passes = sw.solve(0.05, 0.05)
+    assert Xi.shape == (5, 2, 10) and sw.idx.shape == (5, x.shape[0] // 2)
+    for s in range(5):
+        rows = sw.idx[s].long()
+        r = make(2, 3, thr=0.05)
+        from symode_amd.train import train_SINDy
+        train_SINDy(r, x[rows], dx[rows], num_epochs=10, device="cpu", log_interval=100, save_interval=100, save_dir="t",
+                    w_sindy_reg=0.05, threshold=0.05)
+        assert np.array_equal(mask[s].numpy(), r.mask.numpy())
+        assert np.allclose(Xi[s].numpy(), r.Xi.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert len({tuple(sw.idx[s].tolist()) for s in range(5)}) == 5          # every seed has its own subsample
