@@ -85,7 +85,7 @@ int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, in
 /* Same, for n_problems index subsets of ONE shared data set: problem s uses the m points
  * x[idx[s*m + i]], i < m (int32 row indices < n_src; the caller guarantees the range).
  * replaces: the per-seed DataLoader subsample (main.py:36-38) of a seed sweep
- * (run_scripts/*.sh: `for i in {0..49}`) followed by sindy.py:261-288, for all seeds at once. */
+ * (the run_scripts seed loops, `for i in {0..49}`) followed by sindy.py:261-288, for all seeds at once. */
 int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const int* idx, long n_problems, long m, int d,
                            int order, int flags, double* gram_out, void* workspace, size_t workspace_bytes,
                            void* stream);

@@ -12,7 +12,16 @@
 namespace symode {
 
 constexpr int BLOCK = 256;
-constexpr int MAX_GRID_X = 2048;   // 256 CUs x 8 resident workgroups
+// total workgroups of a batched launch are capped near this (256 CUs x 8 resident workgroups x 4);
+// SYMODE_MAX_GRID overrides it for tuning runs
+inline int max_grid_x() {
+    static const int v = [] {
+        const char* e = getenv("SYMODE_MAX_GRID");
+        const int g = e ? atoi(e) : 8192;
+        return g < 256 ? 256 : g;
+    }();
+    return v;
+}
 
 // One row of the dispatch table: everything the C ABI needs for one (D, ORDER, FLAGS).
 struct LibOps {
@@ -52,7 +61,7 @@ inline int grid_x_for(long n, long S, int pts_per_thread_iter) {
         g = (n + 4 * per_block - 1) / (4 * per_block);
         if (g < 512) g = 512;
     }
-    long cap = MAX_GRID_X / (S < 1 ? 1 : S);
+    long cap = max_grid_x() / (S < 1 ? 1 : S);
     if (cap < 2) cap = 2;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -341,6 +350,53 @@ __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restric
                 load_chunk_raw<D, NT>(xs, c, ax);
                 load_chunk_raw<D, NT>(ys, c, ay);
                 chunk(ax, ay);
+            }
+        } else if constexpr (VARIANT == 8) {
+            // LDS-DMA ring: every lane's next NS-1 chunks are in flight as global_load_lds (no VGPRs),
+            // parked at ring[stage][array][thread]; a lane only ever reads back its own slots, so the
+            // only synchronisation is the issuing wave's counted vmcnt (no barrier).
+            constexpr int NS = 4, PER = 2 * NV;                 // DMA instructions per wave per stage
+            __shared__ float4 ring[NS][PER][BLOCK];
+            const int wbase = (threadIdx.x / WAVE) * WAVE;
+            const float4* gx = reinterpret_cast<const float4*>(xs);
+            const float4* gy = reinterpret_cast<const float4*>(ys);
+            const long last = nchunks - 1;
+            auto issue = [&](int st, long cc) {
+                const long cl = cc < last ? cc : last;           // clamp: keeps the vmcnt arithmetic uniform
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(gx + cl * NV + i),
+                        (__attribute__((address_space(3))) void*)&ring[st][i][wbase], 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(gy + cl * NV + i),
+                        (__attribute__((address_space(3))) void*)&ring[st][NV + i][wbase], 16, 0, 0);
+                }
+            };
+            const long c0 = (long)blockIdx.x * BLOCK;            // block-uniform trip count
+            const long iters = nchunks > c0 ? (nchunks - c0 + nthreads - 1) / nthreads : 0;
+            if (iters > 0 && nchunks > 0) {
+#pragma unroll
+                for (int st = 0; st < NS - 1; ++st) issue(st, c + (long)st * nthreads);
+                for (long it = 0; it < iters; ++it) {
+                    const int st = (int)(it % NS);
+                    issue((int)((it + NS - 1) % NS), c + (NS - 1) * nthreads);
+                    // all but the youngest (NS-1) stages' DMAs have landed -> stage `st` is readable
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (NS - 1)) : "memory");
+                    float4 ax[NV], ay[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        const unsigned ax_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)&ring[st][i][threadIdx.x];
+                        const unsigned ay_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)&ring[st][NV + i][threadIdx.x];
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(ax[i]) : "v"(ax_addr) : "memory");
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(ay[i]) : "v"(ay_addr) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c < nchunks) chunk(ax, ay);
+                    c += nthreads;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches
             }
         } else {
             for (; c < nchunks; c += nthreads) {
@@ -656,6 +712,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     switch (loss_grad_variant()) {
         case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
         case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
+        case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
         default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
     }
     SYMODE_LAUNCH_CHECK();
