@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="collective pipeline depth (0: 1 for N=1, 4 otherwise)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
+    ap.add_argument("--force_dist", action="store_true",
+                    help="initialise the RCCL process group and run the collective path even with one rank (self-test)")
     ap.add_argument("--profile", action="store_true",
                     help="profiling run: only the batched steps (no single-problem loop, no CPU baseline), so that "
                          "rocprofv3 --stats averages the headline launches alone")
@@ -80,7 +82,10 @@ def main():
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     import symode_amd
@@ -97,14 +102,14 @@ def main():
     so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
     Q, use_kron = constraint_Q([so2], d, order)
     Q = Q.to(dev)
-    n_chunks = a.chunks or (1 if world == 1 else 4)
+    n_chunks = a.chunks or (4 if use_dist else 1)
     clos = BatchedClosure(x, dx, order, Q=Q, use_kron_product=use_kron, allow_constant=True,
-                          group=dist.group.WORLD if world > 1 else None, n_chunks=n_chunks, engine=eng)
+                          group=dist.group.WORLD if use_dist else None, n_chunks=n_chunks, engine=eng)
     g = torch.Generator(device=dev)
     g.manual_seed(7 + rank)
     beta = torch.randn(S, Q.shape[1], generator=g, device=dev) * 0.3
     const = torch.randn(S, d, 1, generator=g, device=dev) * 0.1
-    if world > 1:                       # all ranks optimise the same coefficients
+    if use_dist:                        # all ranks optimise the same coefficients
         dist.broadcast(beta, 0)
         dist.broadcast(const, 0)
 
@@ -114,7 +119,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -135,7 +140,7 @@ def main():
     for _ in range(a.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -143,7 +148,7 @@ def main():
     assert torch.isfinite(out[0]).all()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -170,8 +175,7 @@ def main():
         single_us = e0.elapsed_time(e1) * 1e3 / reps
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     total_points = float(S) * n_pts * world * a.steps
@@ -191,7 +195,7 @@ def main():
         "config": {"workload": f"damped_oscillator n_ics={a.n_ics} steps={a.n_steps} dim=2 poly-order={order} "
                                f"EquivSINDy-c (so2), {S} (trajectory,seed) problems per GPU resident in HBM; "
                                f"step = closure (Xi from beta, fused Theta+residual+loss+grad kernel, grad->beta"
-                               f"{', RCCL all-reduce of [loss|grad]' if world > 1 else ''})",
+                               f"{', RCCL all-reduce of [loss|grad]' if use_dist else ''})",
                    "points_per_step_per_gpu": S * n_pts, "library_terms": clos.p,
                    "parallelism": f"point-shard x{world}" if world > 1 else "single"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -208,7 +212,7 @@ def main():
         res["speedup_vs_cpu_batched"] = value / res["cpu_baseline"]["value"]
         res["speedup_vs_cpu_single_problem"] = res["single_problem"]["points_per_s"] / res["cpu_baseline"]["value"]
     print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -56,41 +56,122 @@ def train_lassi(*args, **kwargs):
                               'run it with the reference on stock PyTorch-ROCm and load its checkpoints (--load_laligan).')
 
 
+class _HostShadow:
+    """Host-resident optimisation variables of a regressor whose data lives in HBM.
+
+    L-BFGS on a dozen parameters is dozens of tiny tensor ops per inner iteration; on device
+    tensors every one of them is a kernel launch or a sync (measured: 3.6 ms per closure for
+    dosc 50x2500x2, against 12 us of kernel time).  The shadow keeps ``Xi`` (or ``beta``/``const``)
+    and the mask on the host, evaluates the closure with ONE fused launch -- coefficients go up
+    through a pinned buffer, ``[loss | dloss/dXi]`` comes back through another -- and lets autograd
+    carry the gradient through ``get_Xi`` on the host.  ``sync()`` writes the state back into the
+    regressor (called before every print / save / threshold and at the end), so callers see
+    the reference's semantics.
+    """
+
+    def __init__(self, regressor, x, dx, reversed_sym=None):
+        self.reg, self.x, self.dx = regressor, x, dx
+        self.params = [p.detach().cpu().clone().requires_grad_(True) for p in regressor.parameters()]
+        self.mask = regressor.mask.detach().cpu().clone()
+        self.Q = regressor.Q.detach().cpu() if regressor.constraint else None
+        d, p = regressor.mask.shape
+        dev = x.device
+        self.h_xi = torch.empty(d, p).pin_memory()
+        self.d_xi = torch.empty(d, p, device=dev)
+        self.n_out = 1 + d * p
+        self.reversed_sym = reversed_sym                      # (gx, jgx) of the fused reversed regulariser, or None
+        n_terms = 2 if reversed_sym is not None else 1
+        self.d_out = torch.empty(n_terms * self.n_out, device=dev)
+        self.h_out = torch.empty(n_terms * self.n_out).pin_memory()
+
+    def parameters(self):
+        return self.params
+
+    def get_Xi(self):                                                                   # sindy.py:169-176 on the host
+        reg = self.reg
+        if not reg.constraint:
+            return self.params[0]
+        beta, const = self.params
+        if reg.use_kron_product:
+            Xi = (self.Q @ beta).view(reg.latent_dim, -1)
+        else:
+            Xi = (self.Q @ beta).view(-1, reg.latent_dim).transpose(0, 1)
+        if reg.allow_constant:
+            Xi = Xi + torch.cat([const, torch.zeros(Xi.shape[0], Xi.shape[1] - 1)], dim=1)
+        return Xi
+
+    def set_threshold(self, threshold):                                                 # sindy.py:192-194
+        with torch.no_grad():
+            self.mask = torch.logical_and(torch.abs(self.get_Xi()) > threshold, self.mask).float()
+        self.sync()
+
+    def sync(self):
+        with torch.no_grad():
+            for dst, src in zip(self.reg.parameters(), self.params):
+                dst.data.copy_(src.detach())
+            self.reg.mask.data = self.mask.to(self.reg.mask.device)
+
+    def evaluate(self):
+        """Returns (Xi on host with graph, [mse, sym] values, [dmse/dXi, dsym/dXi]) -- one sync."""
+        reg, d, p = self.reg, *self.mask.shape
+        Xi = self.get_Xi()
+        self.h_xi.copy_(Xi.detach())
+        self.d_xi.copy_(self.h_xi, non_blocking=True)
+        n = self.n_out
+        reg.engine.loss_grad(self.x, self.dx, self.d_xi, reg.mask, reg.poly_order, reg.flags,
+                             out=(self.d_out[:1], self.d_out[1:n].view(d, p)))
+        if self.reversed_sym is not None:
+            gx, jgx = self.reversed_sym
+            ls, gs = reg.engine.symreg_reversed(self.x, gx, jgx, self.d_xi, reg.mask, reg.poly_order, reg.flags)
+            self.d_out[n:n + 1].copy_(ls.reshape(1))
+            self.d_out[n + 1:].copy_(gs.reshape(-1))
+        self.h_out.copy_(self.d_out, non_blocking=True)
+        torch.cuda.current_stream(self.x.device).synchronize()
+        vals = [self.h_out[k * n].clone() for k in range(len(self.h_out) // n)]
+        grads = [self.h_out[k * n + 1:(k + 1) * n].view(d, p).clone() for k in range(len(self.h_out) // n)]
+        return Xi, vals, grads
+
+
 def _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, threshold, log_interval, save_interval,
-                 save_dir, print_eq, on_log=None, tol=1e-3):
-    """L-BFGS epochs with convergence-triggered / periodic thresholding       (train.py:692-766, 805-852)."""
-    optimizer = torch.optim.LBFGS(regressor.parameters(), lr=lr_sindy)
-    prev_params = [p.detach().clone() for p in regressor.parameters()]
-    pprev_params = [p.detach().clone() for p in regressor.parameters()]
+                 save_dir, print_eq, on_log=None, tol=1e-3, shadow=None):
+    """L-BFGS epochs with convergence-triggered / periodic thresholding       (train.py:692-766, 805-852).
+    ``shadow`` (optional _HostShadow) owns the optimisation variables instead of the regressor."""
+    P = shadow if shadow is not None else regressor
+    sync = shadow.sync if shadow is not None else (lambda: None)
+    optimizer = torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
+    prev_params = [p.detach().clone() for p in P.parameters()]
+    pprev_params = [p.detach().clone() for p in P.parameters()]
     n_iters = 0
     for epoch in range(num_epochs):
         n_iters += 1
         optimizer.step(lambda: closure(optimizer))
-        if any(torch.isnan(p).any() for p in regressor.parameters()):                 # train.py:697
+        if any(torch.isnan(p).any() for p in P.parameters()):                         # train.py:697
             print(f'NaN encountered at iteration {epoch}; exit training.')
             break
         wandb_log = _as_float(losses)
         with torch.no_grad():
-            param_update_norm = sum(torch.norm(p - q) for p, q in zip(regressor.parameters(), prev_params))
+            param_update_norm = sum(torch.norm(p - q) for p, q in zip(P.parameters(), prev_params))
         if param_update_norm < tol:
-            param_update_norm_2 = sum(torch.norm(p - q) for p, q in zip(regressor.parameters(), pprev_params))
+            param_update_norm_2 = sum(torch.norm(p - q) for p, q in zip(P.parameters(), pprev_params))
             if param_update_norm_2 < tol:                                              # train.py:709-714
                 print(f'Final convergence reached at iteration {epoch}; exit training.')
+                sync()
                 _save(regressor, save_dir, f'regressor_{epoch}.pt')
                 break
             n_iters = 0
-            regressor.set_threshold(threshold)
-            optimizer = torch.optim.LBFGS(regressor.parameters(), lr=lr_sindy)
-            pprev_params = [p.detach().clone() for p in regressor.parameters()]
+            P.set_threshold(threshold)
+            optimizer = torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
+            pprev_params = [p.detach().clone() for p in P.parameters()]
             print(f'Convergence reached at iteration {epoch}; apply parameter thresholding and reset optimizer.')
         elif st_freq > 0 and n_iters % st_freq == 0:                                   # train.py:720-724
             n_iters = 0
-            regressor.set_threshold(threshold)
-            optimizer = torch.optim.LBFGS(regressor.parameters(), lr=lr_sindy)
+            P.set_threshold(threshold)
+            optimizer = torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
             print('Max number of LBFGS iterations reached; apply parameter thresholding and reset optimizer.')
-        prev_params = [p.detach().clone() for p in regressor.parameters()]
+        prev_params = [p.detach().clone() for p in P.parameters()]
 
         if (epoch + 1) % log_interval == 0:
+            sync()
             print(', '.join([f'Epoch {epoch}'] + [f'{k}: {v:.4f}' for k, v in _as_float(losses).items()]))
             if on_log is not None:
                 wandb_log.update(on_log(epoch))
@@ -98,7 +179,9 @@ def _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, thre
                 regressor.print()
         wandb.log(wandb_log)
         if (epoch + 1) % save_interval == 0:
+            sync()
             _save(regressor, save_dir, f'regressor_{epoch}.pt')
+    sync()
 
 
 def train_SIGED_lbfgs(
@@ -164,6 +247,38 @@ def train_SIGED_lbfgs(
         loss.backward()
         return loss
 
+    # Host-resident optimisation variables (see _HostShadow): whenever the closure is made only of fused
+    # kernels -- plain / constrained SINDy, optionally with the reversed regulariser on a frozen autoencoder.
+    shadow = None
+    frozen = not any(p.requires_grad for m in (autoencoder, generator) for p in m.parameters())
+    eligible = (x.is_cuda and not use_latent and kwargs.get('host_lbfgs', True)
+                and (w_sym_reg <= 0.0 or (sym_reg_type == 'r' and frozen)))
+    if eligible:
+        rev = None
+        if w_sym_reg > 0.0:
+            from .model_utils import precompute_symmreg_r
+            gx, jgx = precompute_symmreg_r(x, autoencoder, generator, scale=0.01)
+            rev = (torch.stack(gx).contiguous(), torch.stack(jgx).contiguous())
+        shadow = _HostShadow(regressor, x, dx, reversed_sym=rev)
+
+        def closure(optimizer):                                                        # same terms as train.py:645-690
+            optimizer.zero_grad()
+            Xi, vals, grads = shadow.evaluate()
+            lin = lambda v, g: v + (g * (Xi - Xi.detach())).sum()                      # value + exact first-order term  # noqa: E731
+            losses['loss_sindy_x'] = vals[0]
+            loss = w_sindy_x * lin(vals[0], grads[0])
+            if rev is not None:
+                losses['loss_sym_reg'] = vals[1]
+                loss = loss + w_sym_reg * lin(vals[1], grads[1])
+            if sindy_reg_type == 'l1':
+                loss_sindy_reg = sum(torch.norm(p, 1) for p in shadow.parameters())
+                losses['loss_sindy_reg'] = loss_sindy_reg.detach()
+                loss = loss + w_sindy_reg * loss_sindy_reg
+            elif sindy_reg_type != 'none':
+                raise ValueError(f'Unknown regularization type: {sindy_reg_type}')
+            loss.backward()
+            return loss
+
     def test_log(epoch):                                   # the reference evaluates on the TRAIN batch here (:739-751)
         out = {'test_loss_sindy_z': 0.0, 'test_loss_sindy_x': 0.0}
         n = 0
@@ -180,7 +295,7 @@ def train_SIGED_lbfgs(
         return out
 
     _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, threshold, log_interval, save_interval,
-                 save_dir, print_eq, on_log=test_log)
+                 save_dir, print_eq, on_log=test_log, shadow=shadow)
 
     # (Optional) Phase 2: distill equation from latent to data space                   # train.py:768-852
     if not distill_latent:

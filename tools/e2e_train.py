@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""End-to-end L-BFGS discovery run (train_SIGED_lbfgs) on the GPU next to the CPU oracle's restatement.
+
+    python tools/e2e_train.py [--order 3] [--n_ics 50] [--steps 2500]
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import symode_amd
+from symode_amd import data
+from oracle import sindy_oracle as O
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--n_ics", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2500)
+    ap.add_argument("--epochs", type=int, default=60)
+    ap.add_argument("--skip_cpu", action="store_true")
+    a = ap.parse_args()
+    x, dx = data.make_dataset("dosc", a.n_ics, a.steps, dt=0.02, noise=0.0, seed=0, device="cuda")
+    x, dx = x[0], dx[0]
+    p = symode_amd.library.term_count(2, a.order)
+    torch.manual_seed(0)
+    Xi0 = torch.randn(2, p)
+    ident = torch.nn.Identity()
+    kw = dict(test_loader=[], num_epochs=a.epochs, log_interval=10 ** 9, save_interval=10 ** 9, save_dir="e2e_tmp",
+              autoencoder=ident, generator=ident, regressor_dst=None, use_latent=False, distill_latent=False, lr_sindy=0.1,
+              w_sindy_z=0.0, w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="i", w_sym_reg=0.0,
+              st_freq=50, threshold=0.05, int_t=0.1, int_dt=0.01, print_eq=False)
+    for host in (False, True):
+        for rep in range(2):                       # first run warms up
+            r = symode_amd.SINDyRegression(2, a.order, False, False, threshold=0.05, device="cuda")
+            r.Xi.data = Xi0.cuda()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                symode_amd.train.train_SIGED_lbfgs(train_loader=[(x, dx)], device="cuda", regressor=r, host_lbfgs=host, **kw)
+            torch.cuda.synchronize()
+            t_gpu = time.perf_counter() - t0
+        print(f"GPU train_SIGED_lbfgs host_lbfgs={host}: {t_gpu:.3f} s")
+    print(f"GPU train_SIGED_lbfgs: {t_gpu:.3f} s; mask\n{r.mask.int().cpu().numpy()}\nXi\n{np.round((r.Xi*r.mask).detach().cpu().numpy(), 4)}")
+    if not a.skip_cpu:
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        xc, dxc = x.cpu(), dx.cpu()
+        for rep in range(2):
+            reg = O.OracleRegressor(2, a.order, threshold=0.05, Xi0=Xi0)
+            t0 = time.perf_counter()
+            hist = O.lbfgs_fit(reg, xc, dxc, a.epochs, 0.1, st_freq=50, threshold=0.05)
+            t_cpu = time.perf_counter() - t0
+        print(f"CPU oracle lbfgs_fit ({torch.get_num_threads()} threads): {t_cpu:.3f} s; closures {hist['n_closure']}; "
+              f"same mask: {bool(torch.equal(reg.mask, r.mask.cpu()))}; speedup {t_cpu / t_gpu:.1f}x")
+
+
+if __name__ == "__main__":
+    main()
