@@ -33,6 +33,22 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+class _StdoutToStderr:
+    """fd-level redirect: RCCL prints a version banner on stdout when its communicator is created;
+    the driver wants exactly one JSON line there."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,7 +58,7 @@ def parse():
     ap.add_argument("--n_ics", type=int, default=50)
     ap.add_argument("--n_steps", type=int, default=2500)
     ap.add_argument("--poly_order", type=int, default=5)
-    ap.add_argument("--chunks", type=int, default=0, help="collective pipeline depth (0: 1 for N=1, 4 otherwise)")
+    ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernel (default 1: one collective)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--force_dist", action="store_true",
@@ -86,7 +102,11 @@ def main():
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)                      # creates the RCCL communicator (banner goes to stderr)
+            torch.cuda.synchronize()
 
     import symode_amd
     from symode_amd import data
@@ -102,7 +122,7 @@ def main():
     so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
     Q, use_kron = constraint_Q([so2], d, order)
     Q = Q.to(dev)
-    n_chunks = a.chunks or (4 if use_dist else 1)
+    n_chunks = a.chunks or 1
     clos = BatchedClosure(x, dx, order, Q=Q, use_kron_product=use_kron, allow_constant=True,
                           group=dist.group.WORLD if use_dist else None, n_chunks=n_chunks, engine=eng)
     g = torch.Generator(device=dev)
