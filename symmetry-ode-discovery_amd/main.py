@@ -94,6 +94,10 @@ def main(argv=None):
     print('\n=== Evaluation ===\n')
     true_eq = sindy_truth[args['task']]
     regressor_eval = regressor_dst if args['distill_latent'] else regressor
+    n_terms = regressor_eval.mask.shape[1]
+    if true_eq.shape[1] < n_terms and not (regressor_eval.include_sine or regressor_eval.include_exp):
+        # a higher polynomial order only appends columns: the truth table extends with zeros
+        true_eq = np.concatenate([true_eq, np.zeros((true_eq.shape[0], n_terms - true_eq.shape[1]))], axis=1)
     coef, cf, mse, cf_all, mse_all = eval_sindy_regressor(regressor_eval, true_eq)
     print(f'Correct form: {cf}')
     print(f'MSE: {np.where(cf, mse, 0.0)}')
