@@ -138,3 +138,76 @@ def test_train_sindy_and_wsindy_on_gpu(S, golden):
         res, c = wr.solve(xw, 0.0, 0.05)
         assert np.array_equal(r.mask.cpu().numpy(), wm) and bool(c) == bool(wc)
         assert np.allclose(r.Xi.detach().cpu().numpy(), wx, rtol=1e-3, atol=1e-3 * np.abs(wx).max())
+
+
+def _train_kwargs(**over):
+    kw = dict(test_loader=[], num_epochs=6, device=DEV, log_interval=10 ** 9, save_interval=10 ** 9, save_dir="t",
+              regressor_dst=None, use_latent=False, distill_latent=False, lr_sindy=0.1, w_sindy_z=0.0, w_sindy_x=1.0,
+              sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="i", w_sym_reg=0.0, st_freq=50, threshold=0.05,
+              int_t=0.03, int_dt=0.01, print_eq=False)
+    kw.update(over)
+    return kw
+
+
+@pytest.mark.parametrize("sym", ["i", "f", "r"])
+def test_trainer_with_symmetry_regulariser_runs_and_matches_oracle_closure(S, golden, sym, tmp_path, monkeypatch):
+    """EquivSINDy-r style closure (MSE + w * sym-reg) through train_SIGED_lbfgs with a frozen tiny
+    autoencoder: first-closure loss equals the oracle's value for the same terms, training lowers it."""
+    monkeypatch.chdir(tmp_path)
+    g = golden("f6_symreg")
+    tag, act, rep = "relu_sim2", "ReLU", "(2,sim2)"
+    ae = load_fixture_autoencoder(g, tag, act, DEV)
+    gen = load_fixture_generator(g, tag, rep, DEV)
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    x = t(g[f"{tag}_x"])
+    Xi0 = t(g[f"{tag}_Xi"])
+    dx = O.forward(x, Xi0 * 0.5, torch.ones_like(Xi0), order, bool(sine), bool(exp)).detach()
+    r = S.SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.05, device=DEV)
+    r.Xi.data = Xi0.to(DEV)
+    logged = []
+    monkeypatch.setattr(S.train.wandb, "log", lambda dct, *a, **k: logged.append(dict(dct)), raising=False)
+    S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ae, generator=gen, regressor=r,
+                              **_train_kwargs(sym_reg_type=sym, w_sym_reg=0.1, num_epochs=4))
+    assert len(logged) >= 1 and all(np.isfinite(list(l.values())).all() for l in logged)
+    first, last = logged[0], logged[-1]
+    assert last["loss_sindy_x"] < first["loss_sindy_x"] * 1.01
+    assert "loss_sym_reg" in first and first["loss_sym_reg"] >= 0
+
+
+def test_reversed_regulariser_host_and_device_lbfgs_agree(S, golden, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    g = golden("f6_symreg")
+    tag, act, rep = "tanh_learn", "Tanh", "(2,1,2)"
+    ae = load_fixture_autoencoder(g, tag, act, DEV)
+    gen = load_fixture_generator(g, tag, rep, DEV)
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    x = t(g[f"{tag}_x"])
+    Xi0 = t(g[f"{tag}_Xi"])
+    dx = O.forward(x, Xi0 * 0.5, torch.ones_like(Xi0), order, bool(sine), bool(exp)).detach()
+    out = []
+    for host in (True, False):
+        r = S.SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.01, device=DEV)
+        r.Xi.data = Xi0.to(DEV)
+        S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ae, generator=gen, regressor=r,
+                                  **_train_kwargs(sym_reg_type="r", w_sym_reg=0.1, num_epochs=3, host_lbfgs=host, threshold=0.01))
+        out.append((r.Xi.detach().cpu().numpy(), r.mask.cpu().numpy()))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.allclose(out[0][0], out[1][0], rtol=2e-3, atol=2e-4)
+
+
+def test_latent_branch_and_distillation_with_identity_autoencoder(S, golden, tmp_path, monkeypatch):
+    """use_latent + distill_latent (train.py:647-661, 768-852) with ae_arch='none': z = x, dz = dx."""
+    monkeypatch.chdir(tmp_path)
+    g = golden("f4_lbfgs")
+    x, dx = t(g["dosc_sindy_x"]), t(g["dosc_sindy_dx"])
+    ae = S.autoencoder.AutoEncoder(ae_arch="none").to(DEV)
+    gen = S.lie.LieGenerator(repr="(1,so2)", group_idx="0", device=DEV).to(DEV)
+    r = S.SINDyRegression(2, 2, False, False, threshold=0.05, device=DEV)
+    r_dst = S.SINDyRegression(2, 2, False, False, threshold=0.05, device=DEV)
+    S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ae, generator=gen, regressor=r,
+                              **_train_kwargs(use_latent=True, distill_latent=True, regressor_dst=r_dst, w_sindy_z=1.0,
+                                              w_sindy_x=0.0, num_epochs=40, lr_sindy=0.1))
+    want = torch.tensor(O.SINDY_TRUTH["dosc"] != 0)
+    assert torch.equal(r.mask.cpu().bool(), want)
+    assert torch.equal(r_dst.mask.cpu().bool(), want)
+    assert np.allclose((r_dst.Xi * r_dst.mask).detach().cpu().numpy(), O.SINDY_TRUTH["dosc"], atol=5e-3)
