@@ -1,0 +1,121 @@
+"""Parity at the BASELINE.json configurations, full sizes, against the CPU oracle run live on the
+same inputs (the oracle finishes each of these in seconds): identical recovered sparsity masks,
+coefficients within tolerance.  Inputs are synthetic (the reference's data files are not shipped):
+RK4 orbits of the reference's systems made by symode_amd.data (checked against the oracle's RK4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sindy_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+torch.set_num_threads(8)
+
+
+@pytest.fixture(scope="module")
+def S():
+    import symode_amd
+    assert torch.cuda.is_available()
+    return symode_amd
+
+
+def _lbfgs(S, r, x, dx, lr, st_freq, thr, epochs, **kw):
+    ident = torch.nn.Identity()
+    S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], test_loader=[], num_epochs=epochs, device=DEV, log_interval=10 ** 9,
+                              save_interval=10 ** 9, save_dir="bl", autoencoder=ident, generator=ident, regressor=r,
+                              regressor_dst=None, use_latent=False, distill_latent=False, lr_sindy=lr, w_sindy_z=0.0,
+                              w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="i", w_sym_reg=0.0,
+                              st_freq=st_freq, threshold=thr, int_t=0.1, int_dt=0.01, print_eq=False, **kw)
+
+
+def test_config0_dosc_50x2500x2_order3_lbfgs(S, tmp_path, monkeypatch):
+    """configs[0]: damped oscillator n_ics=50 steps=2500 dim=2, plain SINDy with L-BFGS (lr 0.1, thr 5e-2, st_freq 50)."""
+    monkeypatch.chdir(tmp_path)
+    x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=0.0, seed=0, device=DEV)
+    x, dx = x[0], dx[0]
+    assert x.shape == (125000, 2)
+    torch.manual_seed(0)
+    Xi0 = torch.randn(2, 10)
+    r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV)
+    r.Xi.data = Xi0.to(DEV)
+    _lbfgs(S, r, x, dx, 0.1, 50, 0.05, 60)
+    reg = O.OracleRegressor(2, 3, threshold=0.05, Xi0=Xi0)
+    O.lbfgs_fit(reg, x.cpu(), dx.cpu(), 60, 0.1, st_freq=50, threshold=0.05)
+    assert torch.equal(r.mask.cpu(), reg.mask)                                   # identical sparsity mask
+    want = (reg.Xi * reg.mask).detach().numpy()
+    assert np.allclose((r.Xi * r.mask).detach().cpu().numpy(), want, rtol=1e-3, atol=2e-4)
+    truth = np.zeros((2, 10))
+    truth[:, :6] = O.SINDY_TRUTH["dosc"]
+    assert np.array_equal(r.mask.cpu().numpy() != 0, truth != 0)                 # and it is the true equation
+
+
+def test_config1_dosc_order5_equivariant_so2(S, tmp_path, monkeypatch):
+    """configs[1]: same data, poly-order 5 (p = 21), EquivSINDy-c with L = so2 (lr 1.0, thr 1e-2, st_freq 100)."""
+    monkeypatch.chdir(tmp_path)
+    x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=0.0, seed=0, device=DEV)
+    x, dx = x[0], dx[0]
+    so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
+    torch.manual_seed(1)
+    r = S.SINDyRegression(2, 5, False, False, L_list=[so2], threshold=0.01, device=DEV, constrain_constant=False)
+    reg = O.OracleRegressor(2, 5, L_list=[so2], threshold=0.01, beta0=r.beta.detach().cpu(), const0=r.const.detach().cpu())
+    reg.Q = r.Q.cpu()                                                            # same SVD gauge on both sides
+    assert reg.use_kron_product == r.use_kron_product
+    _lbfgs(S, r, x, dx, 1.0, 100, 0.01, 60)
+    O.lbfgs_fit(reg, x.cpu(), dx.cpu(), 60, 1.0, st_freq=100, threshold=0.01)
+    assert torch.equal(r.mask.cpu(), reg.mask)
+    got, want = (r.get_Xi() * r.mask).detach().cpu().numpy(), (reg.get_Xi() * reg.mask).detach().numpy()
+    assert np.allclose(got, want, rtol=1e-3, atol=2e-4)
+    assert np.allclose(got[:, 1:3], [[-0.1, -1.0], [1.0, -0.1]], atol=2e-3)
+
+
+def test_config3_selkov_64_seed_sweep_full_size(S):
+    """configs[3]: selkov n_ics=10 x 10^4 steps, order 3, 64 seeds x 50 % subsamples, STLSQ (gamma 0, thr 7.5e-2)."""
+    x, dx = S.data.make_dataset("selkov", 10, 10000, dt=0.002, noise=0.0, seed=2, device=DEV)
+    x, dx = x[0], dx[0]
+    sw = S.sweep.SeedSweepSTLSQ(x, dx, 3, n_seeds=64, subsample=0.5, seed0=0)
+    Xi, mask, passes = sw.solve(0.0, 0.075)
+    assert sw.idx.shape == (64, 50000)
+    xc, dxc = x.cpu(), dx.cpu()
+    for s in (0, 31, 63):
+        rows = sw.idx[s].long().cpu()
+        reg = O.OracleRegressor(2, 3, threshold=0.075, Xi0=torch.zeros(2, 10))
+        hist = O.stlsq_until_converged(reg, xc[rows], dxc[rows], 10, 0.0, 0.075)
+        assert np.array_equal(mask[s].numpy(), reg.mask.numpy()), s               # identical mask, same rank-truncated solve
+        want = reg.Xi.detach().numpy()
+        assert np.allclose(Xi[s].numpy(), want, rtol=2e-4, atol=2e-4 * np.abs(want).max()), s
+    # with the full-rank driver (what the reference computes on a GPU) every seed recovers the true equation
+    Xi2, mask2, _ = sw.solve(0.0, 0.075, lstsq_driver="gels")
+    assert all(np.array_equal(mask2[s].numpy() != 0, O.SINDY_TRUTH["selkov"] != 0) for s in range(64))
+    assert np.allclose(Xi2.numpy(), np.broadcast_to(O.SINDY_TRUTH["selkov"], (64, 2, 10)), atol=2e-3)
+
+
+def test_config2_lv_exp_library_symreg_reversed_closure(S):
+    """configs[2] shape: lv, order 2 + exp (p = 8), n_ics=200 x 10^4 at 1 % = 20 000 points; the closure with the
+    reversed regulariser (random frozen tiny autoencoder) equals the oracle's MSE + w * sym-reg and its gradient."""
+    from tests.helpers import load_fixture_autoencoder, load_fixture_generator, t
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f6_symreg.npz"))
+    ae = load_fixture_autoencoder(g, "tanh_learn", "Tanh", DEV)
+    gen = load_fixture_generator(g, "tanh_learn", "(2,1,2)", DEV)
+    x, dx = S.data.make_dataset("lv", 200, 10000, dt=0.002, noise=0.0, seed=4, device=DEV)
+    gsel = torch.Generator().manual_seed(0)
+    rows = torch.randperm(x.shape[1], generator=gsel)[:20000].to(DEV)
+    x, dx = x[0][rows].contiguous(), dx[0][rows].contiguous()
+    r = S.SINDyRegression(2, 2, False, True, threshold=0.15, device=DEV)
+    torch.manual_seed(3)
+    r.Xi.data = (torch.randn(2, 8) * 0.3).to(DEV)
+    loss = r.mse_loss(x, dx) + 0.1 * S.model_utils.symmreg_r(x, ae, gen, h=r, require_grad=True)
+    loss.backward()
+    # oracle: same terms on the CPU, (g(x), J_g) from the same frozen autoencoder
+    from tests.helpers import TinyAE
+    tae = TinyAE(g, "tanh_learn", "Tanh")
+    gel = [t(e) for e in g["tanh_learn_gelems_r"]]
+    xc, dxc = x.cpu(), dx.cpu()
+    reg = O.OracleRegressor(2, 2, False, True, Xi0=r.Xi.detach().cpu())
+    gx, Jgx = O.precompute_group_jacobians(xc, tae.encode, tae.decode, tae.z_mean, gel)
+    lo = torch.nn.functional.mse_loss(reg(xc), dxc) + 0.1 * O.symreg_reversed_precomputed(xc, gx, Jgx, reg)
+    lo.backward()
+    assert np.isclose(loss.item(), lo.item(), rtol=2e-5)
+    gw = reg.Xi.grad.numpy()
+    assert np.abs(r.Xi.grad.cpu().numpy() - gw).max() <= 5e-5 * np.abs(gw).max()
