@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2500)
     ap.add_argument("--epochs", type=int, default=60)
     ap.add_argument("--skip_cpu", action="store_true")
+    ap.add_argument("--sweep", type=int, default=0, help="also run an S-seed batched L-BFGS sweep (own data per seed)")
     a = ap.parse_args()
     x, dx = data.make_dataset("dosc", a.n_ics, a.steps, dt=0.02, noise=0.0, seed=0, device="cuda")
     x, dx = x[0], dx[0]
@@ -60,5 +61,34 @@ def main():
               f"same mask: {bool(torch.equal(reg.mask, r.mask.cpu()))}; speedup {t_cpu / t_gpu:.1f}x")
 
 
+def sweep(a):
+    from symode_amd.batched import BatchedClosure
+    from symode_amd.sweep import SeedSweepLBFGS
+    S = a.sweep
+    X, DX = data.make_dataset("dosc", a.n_ics, a.steps, dt=0.02, noise=0.0, seed=10, device="cuda", n_problems=S)
+    p = symode_amd.library.term_count(2, a.order)
+    torch.manual_seed(0)
+    inits = torch.randn(S, 2 * p, device="cuda")
+    sw = SeedSweepLBFGS(BatchedClosure(X, DX, a.order), 0.1, 0.05, 50)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = sw.fit(inits, a.epochs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    truth = torch.zeros(2, p, dtype=torch.bool)
+    truth[:, 1:3] = True
+    ok = int(sum(torch.equal(out["mask"][s].cpu().bool(), truth) for s in range(S)))
+    print(f"sweep: {S} seeds x {a.n_ics * a.steps} points, order {a.order}: {dt:.3f} s total = {dt / S * 1e3:.2f} ms/seed; "
+          f"correct form {ok}/{S}; finished {int(out['finished'].sum())}/{S}; max epochs {int(out['epochs'].max())}")
+
+
 if __name__ == "__main__":
     main()
+    _a = argparse.ArgumentParser()
+    for _n, _t, _d in [("--order", int, 3), ("--n_ics", int, 50), ("--steps", int, 2500), ("--epochs", int, 60), ("--sweep", int, 0)]:
+        _a.add_argument(_n, type=_t, default=_d)
+    _a.add_argument("--skip_cpu", action="store_true")
+    _args = _a.parse_args()
+    if _args.sweep:
+        sweep(_args)
