@@ -204,7 +204,12 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("loss_grad_bytes_per_launch")
+            rec = json.load(open(pmc))
+            per_point = rec.get("loss_grad_bytes_per_point")
+            if per_point is not None and abs(rec.get("points_per_launch", 0) - (S / launches_per_step) * n_pts) < 1:
+                traffic = rec["loss_grad_bytes_per_launch"]          # PMC pass taken on this very launch shape
+            elif per_point is not None:
+                traffic = per_point * (S / launches_per_step) * n_pts  # scaled from the profiled launch (streaming kernel)
         except Exception:
             traffic = None
     res = {

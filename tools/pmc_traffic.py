@@ -4,7 +4,7 @@ traffic of the dominant kernel, with the gfx950 corrections of MI355X_MICROARCH.
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE counts exactly half of a wide (16 B/lane) coalesced
 streaming read, so it is doubled; WRITE_SIZE is taken as is.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <total work-items> > profiles/pmc_traffic.json
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <total work-items> <points per launch> > profiles/pmc_traffic.json
 """
 import csv
 import glob
@@ -28,6 +28,7 @@ def collect(d, counter, needle, grid_y):
 def main():
     fetch_dir, write_dir, needle = sys.argv[1], sys.argv[2], sys.argv[3]
     grid_y = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    points = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     f = collect(fetch_dir, "FETCH_SIZE", needle, grid_y)
     w = collect(write_dir, "WRITE_SIZE", needle, grid_y)
     if not f or not w:
@@ -39,6 +40,8 @@ def main():
         "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts half of a 16 B/lane stream); "
                       "write bytes = WRITE_SIZE x 1024",
         "loss_grad_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
+        "points_per_launch": points,
+        "loss_grad_bytes_per_point": (2 * fetch_kib * 1024 + write_kib * 1024) / points if points else None,
     }
     print(json.dumps(out, indent=1))
 
