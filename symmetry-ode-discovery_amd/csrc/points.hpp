@@ -18,11 +18,12 @@ struct Chunk {
 template <int D>
 __device__ __forceinline__ void load_chunk(const float* __restrict__ a, long c, float (&p)[Chunk<D>::PPT][D]) {
     constexpr int NV = Chunk<D>::NV;
-    const float4* q = reinterpret_cast<const float4*>(a) + c * NV;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v* q = reinterpret_cast<const f4v*>(a) + c * NV;
     float f[NV * 4];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const float4 v = q[i];
+        const f4v v = __builtin_nontemporal_load(q + i);          // streamed once
         f[4 * i + 0] = v.x;
         f[4 * i + 1] = v.y;
         f[4 * i + 2] = v.z;
@@ -99,7 +100,12 @@ __device__ __forceinline__ void for_each_point(long N, bool vec, ChunkBody chunk
     const long nthreads = (long)gridDim.x * BLOCK;
     if (vec) {
         const long nchunks = N / PPT;
-        for (long c = tid; c < nchunks; c += nthreads) chunk_body(c);
+        long c = tid;
+        for (; c + nthreads < nchunks; c += 2 * nthreads) {      // two independent chunks per step: more bytes in flight
+            chunk_body(c);
+            chunk_body(c + nthreads);
+        }
+        if (c < nchunks) chunk_body(c);
         const long n = nchunks * PPT + tid;
         if (n < N) point_body(n);
     } else {
