@@ -172,7 +172,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
+    kern_all = sorted(e0.elapsed_time(e1) for e0, e1 in events)
+    kern_ms = sum(kern_all) / max(len(kern_all), 1)
     launches_per_step = len(events) // max(a.steps, 1)
     bytes_per_launch = (S / launches_per_step) * n_pts * (2 * 4 * d)        # read x and dx once: 16 B/point at d=2
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -225,7 +226,8 @@ def main():
                    "parallelism": f"point-shard x{world}" if world > 1 else "single"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "loss_grad_kernel<Library<2,5,0>> (+ finalize)", "kernel_ms": kern_ms,
+                     "kernel": "loss_grad_kernel<Library<2,5,0>> (+ finalize)", "kernel_ms": kern_ms, "kernel_ms_min": kern_all[0], "kernel_ms_median": kern_all[len(kern_all) // 2],
+                     "kernel_ms_max": kern_all[-1],
                      "bytes_per_launch": bytes_per_launch, "launches_per_step": launches_per_step},
         "single_problem": {"shape": f"{a.n_ics}x{a.n_steps}x2", "latency_us": single_us,
                            "points_per_s": n_pts / (single_us * 1e-6)},
