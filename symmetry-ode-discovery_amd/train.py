@@ -69,11 +69,22 @@ class _HostShadow:
     the reference's semantics.
     """
 
-    def __init__(self, regressor, x, dx, reversed_sym=None):
+    def __init__(self, regressor, x, dx, reversed_sym=None, numpy_vars=True):
         self.reg, self.x, self.dx = regressor, x, dx
         self.params = [p.detach().cpu().clone().requires_grad_(True) for p in regressor.parameters()]
+        # numpy mode: ONE flat float32 vector aliases every host parameter (torch views of the same memory)
+        self.flat = None
+        if numpy_vars:
+            sizes = [p.numel() for p in self.params]
+            self.flat = np.concatenate([p.detach().numpy().reshape(-1) for p in self.params]).astype(np.float32)
+            off, views = 0, []
+            for p, n in zip(self.params, sizes):
+                views.append(torch.from_numpy(self.flat[off:off + n]).view(p.shape))
+                off += n
+            self.params = views                               # plain tensors sharing memory with self.flat
         self.mask = regressor.mask.detach().cpu().clone()
         self.Q = regressor.Q.detach().cpu() if regressor.constraint else None
+        self._Qnp = self.Q.numpy() if self.Q is not None else None
         d, p = regressor.mask.shape
         dev = x.device
         self.h_xi = torch.empty(d, p).pin_memory()
@@ -111,6 +122,16 @@ class _HostShadow:
                 dst.data.copy_(src.detach())
             self.reg.mask.data = self.mask.to(self.reg.mask.device)
 
+    def grad_to_flat(self, g_xi):
+        """Chain rule of get_Xi: dL/d(flat parameters) from dL/dXi (d, p), as numpy float32."""
+        reg = self.reg
+        if not reg.constraint:
+            return g_xi.reshape(-1)
+        G = g_xi if reg.use_kron_product else g_xi.T
+        g_beta = self._Qnp.T @ G.reshape(-1)
+        g_const = g_xi[:, 0] if reg.allow_constant else np.zeros(reg.latent_dim, dtype=np.float32)
+        return np.concatenate([g_beta, g_const]).astype(np.float32)
+
     def evaluate(self):
         """Returns (Xi on host with graph, [mse, sym] values, [dmse/dXi, dsym/dXi]) -- one sync."""
         reg, d, p = self.reg, *self.mask.shape
@@ -132,19 +153,101 @@ class _HostShadow:
         return Xi, vals, grads
 
 
+class _NumpyLBFGS:
+    """torch.optim.LBFGS (no line search, default tolerances) on one flat float32 numpy vector.
+
+    Same update rules, history handling and stopping tests as torch/optim/lbfgs.py, statement by
+    statement (see also sweep.BatchedLBFGS); exists because at 12-42 parameters torch's tensor
+    bookkeeping (~0.4 ms per inner iteration) costs 10x the fused closure itself.
+    ``closure(x) -> (loss float, grad float32 array)``.
+    """
+
+    def __init__(self, x, lr, max_iter=20, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100):
+        self.x, self.lr, self.max_iter = x, np.float32(lr), max_iter
+        self.tol_g, self.tol_c, self.H = tolerance_grad, tolerance_change, history_size
+        self.n_iter = 0
+        self.d = self.t = self.prev_g = self.prev_loss = None
+        self.old_dirs, self.old_stps, self.ro, self.H_diag = [], [], [], np.float32(1.0)
+
+    def step(self, closure):
+        f32 = np.float32
+        loss, g = closure(self.x)
+        orig = loss
+        if np.abs(g).max() <= self.tol_g:
+            return orig
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            self.n_iter += 1
+            if self.n_iter == 1:
+                self.d = -g
+                self.old_dirs, self.old_stps, self.ro, self.H_diag = [], [], [], f32(1.0)
+            else:
+                y = g - self.prev_g
+                s = self.d * self.t
+                ys = f32(np.dot(y, s))
+                if ys > 1e-10:
+                    if len(self.old_dirs) == self.H:
+                        self.old_dirs.pop(0)
+                        self.old_stps.pop(0)
+                        self.ro.pop(0)
+                    self.old_dirs.append(y)
+                    self.old_stps.append(s)
+                    self.ro.append(f32(1.0) / ys)
+                    self.H_diag = ys / f32(np.dot(y, y))
+                num_old = len(self.old_dirs)
+                al = [None] * num_old
+                q = -g
+                for i in range(num_old - 1, -1, -1):
+                    al[i] = f32(np.dot(self.old_stps[i], q)) * self.ro[i]
+                    q = q - al[i] * self.old_dirs[i]
+                r = q * self.H_diag
+                for i in range(num_old):
+                    be_i = f32(np.dot(self.old_dirs[i], r)) * self.ro[i]
+                    r = r + self.old_stps[i] * (al[i] - be_i)
+                self.d = r.astype(f32)
+            self.prev_g = g.copy()
+            self.prev_loss = loss
+            if self.n_iter == 1:
+                self.t = f32(min(1.0, 1.0 / float(np.abs(g).sum()))) * self.lr
+            else:
+                self.t = self.lr
+            gtd = f32(np.dot(g, self.d))
+            if gtd > -self.tol_c:
+                break
+            self.x += self.t * self.d
+            if n_iter != self.max_iter:
+                loss, g = closure(self.x)
+                opt_cond = np.abs(g).max() <= self.tol_g
+            else:
+                break
+            if opt_cond:
+                break
+            if np.abs(self.d * self.t).max() <= self.tol_c:
+                break
+            if abs(loss - self.prev_loss) < self.tol_c:
+                break
+        return orig
+
+
 def _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, threshold, log_interval, save_interval,
                  save_dir, print_eq, on_log=None, tol=1e-3, shadow=None):
     """L-BFGS epochs with convergence-triggered / periodic thresholding       (train.py:692-766, 805-852).
     ``shadow`` (optional _HostShadow) owns the optimisation variables instead of the regressor."""
     P = shadow if shadow is not None else regressor
     sync = shadow.sync if shadow is not None else (lambda: None)
-    optimizer = torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
+    fast = shadow is not None and shadow.flat is not None          # numpy variables + numpy L-BFGS
+
+    def new_optimizer():
+        return _NumpyLBFGS(shadow.flat, lr_sindy) if fast else torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
+
+    optimizer = new_optimizer()
     prev_params = [p.detach().clone() for p in P.parameters()]
     pprev_params = [p.detach().clone() for p in P.parameters()]
     n_iters = 0
     for epoch in range(num_epochs):
         n_iters += 1
-        optimizer.step(lambda: closure(optimizer))
+        optimizer.step(closure if fast else (lambda: closure(optimizer)))
         if any(torch.isnan(p).any() for p in P.parameters()):                         # train.py:697
             print(f'NaN encountered at iteration {epoch}; exit training.')
             break
@@ -160,13 +263,13 @@ def _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, thre
                 break
             n_iters = 0
             P.set_threshold(threshold)
-            optimizer = torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
+            optimizer = new_optimizer()
             pprev_params = [p.detach().clone() for p in P.parameters()]
             print(f'Convergence reached at iteration {epoch}; apply parameter thresholding and reset optimizer.')
         elif st_freq > 0 and n_iters % st_freq == 0:                                   # train.py:720-724
             n_iters = 0
             P.set_threshold(threshold)
-            optimizer = torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
+            optimizer = new_optimizer()
             print('Max number of LBFGS iterations reached; apply parameter thresholding and reset optimizer.')
         prev_params = [p.detach().clone() for p in P.parameters()]
 
@@ -247,6 +350,10 @@ def train_SIGED_lbfgs(
         loss.backward()
         return loss
 
+    # numpy_lbfgs=True additionally swaps torch.optim.LBFGS for the numpy restatement (_NumpyLBFGS): 2.7x faster end
+    # to end, same results on well-conditioned problems, but NOT the default: on ill-conditioned libraries (selkov,
+    # cond 9e3, lr 1.0, no line search) the trajectory is chaotic in the last bits of every dot product and only
+    # torch's own optimiser reproduces the reference's recorded run bit-for-bit in its mask.
     # Host-resident optimisation variables (see _HostShadow): whenever the closure is made only of fused
     # kernels -- plain / constrained SINDy, optionally with the reversed regulariser on a frozen autoencoder.
     shadow = None
@@ -259,7 +366,27 @@ def train_SIGED_lbfgs(
             from .model_utils import precompute_symmreg_r
             gx, jgx = precompute_symmreg_r(x, autoencoder, generator, scale=0.01)
             rev = (torch.stack(gx).contiguous(), torch.stack(jgx).contiguous())
-        shadow = _HostShadow(regressor, x, dx, reversed_sym=rev)
+        shadow = _HostShadow(regressor, x, dx, reversed_sym=rev, numpy_vars=kwargs.get('numpy_lbfgs', False))
+
+        def closure_np(flat):                                                          # numpy variables: (loss, flat gradient)
+            with torch.no_grad():
+                Xi, vals, grads = shadow.evaluate()
+            losses['loss_sindy_x'] = vals[0]
+            loss = w_sindy_x * float(vals[0])
+            g_xi = w_sindy_x * grads[0].numpy()
+            if rev is not None:
+                losses['loss_sym_reg'] = vals[1]
+                loss += w_sym_reg * float(vals[1])
+                g_xi = g_xi + w_sym_reg * grads[1].numpy()
+            g = shadow.grad_to_flat(g_xi.astype(np.float32))
+            if sindy_reg_type == 'l1':
+                l1 = float(np.abs(flat).sum())
+                losses['loss_sindy_reg'] = l1
+                loss += w_sindy_reg * l1
+                g = g + np.float32(w_sindy_reg) * np.sign(flat)
+            elif sindy_reg_type != 'none':
+                raise ValueError(f'Unknown regularization type: {sindy_reg_type}')
+            return loss, g.astype(np.float32)
 
         def closure(optimizer):                                                        # same terms as train.py:645-690
             optimizer.zero_grad()
@@ -294,6 +421,8 @@ def train_SIGED_lbfgs(
         print(', '.join([f'Epoch {epoch}'] + [f'{k}: {v:.4f}' for k, v in out.items()]))
         return out
 
+    if shadow is not None and shadow.flat is not None:
+        closure = closure_np
     _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, threshold, log_interval, save_interval,
                  save_dir, print_eq, on_log=test_log, shadow=shadow)
 
