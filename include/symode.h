@@ -128,6 +128,15 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
                    int flags, const float* xi, const float* mask, float* grad_x, float* grad_v, float* grad_xi,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* L-BFGS search direction d = -H g (two-loop recursion) for n_problems independent problems of n <= 256
+ * parameters: curvature pairs in ring buffers old_dirs / old_stps (S, history, n), ro (S, history), with
+ * per-problem `head` (oldest slot) and `count` (pairs stored), int64; h_diag (S) scales the initial Hessian.
+ * replaces: the history loops of torch.optim.LBFGS.step that train.py:630-695 runs per seed and per
+ * inner iteration (new: the reference sweeps seeds as separate processes). */
+int symode_lbfgs_direction(const float* g, const float* old_dirs, const float* old_stps, const float* ro,
+                           const long* head, const long* count, const float* h_diag, long n_problems, int n,
+                           int history, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

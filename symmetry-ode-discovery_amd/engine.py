@@ -45,6 +45,8 @@ _SIGNATURES = {
                                    c_void_p, c_void_p]),
     "symode_jvp_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_lbfgs_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
+                                       c_int, c_void_p, c_void_p]),
 }
 
 ABI_VERSION = 1
@@ -301,6 +303,21 @@ class HipEngine:
                                             self._ptr(gxi), self._ptr(ws), ws.numel() * 8, self._stream(x)),
                     "symode_jvp_vjp")
         return gx, gv, gxi
+
+
+    def lbfgs_direction(self, g, old_dirs, old_stps, ro, head, count, h_diag):
+        """d = -H g by the two-loop recursion for S problems at once (ring-buffered curvature pairs)."""
+        g = self._dev(g, "g")
+        S, n = g.shape
+        H = old_dirs.shape[1]
+        out = torch.empty_like(g)
+        self._check(self.lib.symode_lbfgs_direction(self._ptr(g), self._ptr(self._dev(old_dirs, "old_dirs")),
+                                                    self._ptr(self._dev(old_stps, "old_stps")), self._ptr(self._dev(ro, "ro")),
+                                                    self._ptr(self._dev(head, "head", torch.int64)),
+                                                    self._ptr(self._dev(count, "count", torch.int64)),
+                                                    self._ptr(self._dev(h_diag, "h_diag")), S, n, H, self._ptr(out),
+                                                    self._stream(g)), "symode_lbfgs_direction")
+        return out
 
 
 _ENGINE = None

@@ -78,104 +78,119 @@ class BatchedLBFGS:
     """torch.optim.LBFGS (no line search), restated for S independent problems stepped in lockstep.
 
     Every problem keeps its own state (iteration count, direction, step, curvature history, scale of the
-    initial Hessian) in padded (S, ...) tensors; one ``step`` evaluates the closure for all problems with
-    one fused kernel launch per inner iteration and applies, per problem, exactly the update rules and
+    initial Hessian) in (S, ...) tensors; one ``step`` evaluates the closure of all problems with one
+    fused kernel launch per inner iteration and applies, per problem, exactly the update rules and
     stopping tests of torch/optim/lbfgs.py (defaults: max_iter 20, tolerance_grad 1e-7, tolerance_change
     1e-9, history 100).  Problems that stop early simply stop changing.
+
+    Everything is mask arithmetic -- no host synchronisation inside ``step`` -- and the two-loop recursion
+    over the curvature pairs (ring buffers with per-problem head / count) is ONE kernel, a wavefront per
+    problem (symode_lbfgs_direction), when the variables live on the GPU.
     """
 
-    def __init__(self, params, lr, max_iter=20, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100):
+    def __init__(self, params, lr, max_iter=20, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, engine=None):
         self.P = params                                   # (S, n), updated in place
         S, n = params.shape
         self.lr, self.max_iter, self.tol_g, self.tol_c, self.H = lr, max_iter, tolerance_grad, tolerance_change, history_size
         dev, dt = params.device, params.dtype
+        self.engine = engine if (engine is not None and params.is_cuda and n <= 256 and history_size <= 128) else None
         self.n_iter = torch.zeros(S, dtype=torch.long, device=dev)
         self.d = torch.zeros(S, n, device=dev, dtype=dt)
         self.t = torch.zeros(S, device=dev, dtype=dt)
         self.old_dirs = torch.zeros(S, history_size, n, device=dev, dtype=dt)
         self.old_stps = torch.zeros(S, history_size, n, device=dev, dtype=dt)
         self.ro = torch.zeros(S, history_size, device=dev, dtype=dt)
-        self.hist = torch.zeros(S, dtype=torch.long, device=dev)
+        self.head = torch.zeros(S, dtype=torch.long, device=dev)       # oldest stored pair
+        self.hist = torch.zeros(S, dtype=torch.long, device=dev)       # number of stored pairs
         self.H_diag = torch.ones(S, device=dev, dtype=dt)
         self.prev_g = torch.zeros(S, n, device=dev, dtype=dt)
         self.prev_loss = torch.zeros(S, device=dev, dtype=dt)
+        self._rows = torch.arange(S, device=dev)
 
     def reset(self, which):
         """Fresh optimiser for the selected problems (the reference re-creates LBFGS after thresholding)."""
-        self.n_iter[which] = 0
-        self.hist[which] = 0
-        self.H_diag[which] = 1.0
+        z = torch.zeros_like(self.n_iter)
+        self.n_iter = torch.where(which, z, self.n_iter)
+        self.hist = torch.where(which, z, self.hist)
+        self.head = torch.where(which, z, self.head)
+        self.H_diag = torch.where(which, torch.ones_like(self.H_diag), self.H_diag)
+
+    def _direction(self, g):
+        if self.engine is not None:
+            return self.engine.lbfgs_direction(g, self.old_dirs, self.old_stps, self.ro, self.head, self.hist, self.H_diag)
+        S = g.shape[0]
+        num_old = int(self.hist.max().item())
+        q = -g
+        al = torch.zeros(S, max(num_old, 1), device=g.device, dtype=g.dtype)
+        for k in range(num_old - 1, -1, -1):                               # logical slot k of every problem
+            live = (k < self.hist).to(g.dtype)
+            slot = (self.head + k) % self.H
+            a = (self.old_stps[self._rows, slot] * q).sum(1) * self.ro[self._rows, slot] * live
+            al[:, k] = a
+            q = q - a[:, None] * self.old_dirs[self._rows, slot]
+        r = q * self.H_diag[:, None]
+        for k in range(num_old):
+            live = (k < self.hist).to(g.dtype)
+            slot = (self.head + k) % self.H
+            be = (self.old_dirs[self._rows, slot] * r).sum(1) * self.ro[self._rows, slot] * live
+            r = r + self.old_stps[self._rows, slot] * ((al[:, k] - be) * live)[:, None]
+        return r
 
     @torch.no_grad()
     def step(self, closure, frozen=None):
         """closure(P) -> (loss (S,), grad (S, n)).  ``frozen`` (S,) bool: problems that must not move."""
-        P, S = self.P, self.P.shape[0]
+        P = self.P
         loss, g = closure(P)
         loss, g = loss.clone(), g.clone()
         act = g.abs().amax(dim=1) > self.tol_g                              # optimality test
         if frozen is not None:
-            act &= ~frozen
-        idx = torch.arange(S, device=P.device)
+            act = act & ~frozen
+        one = torch.ones_like(self.n_iter)
         for it in range(1, self.max_iter + 1):
-            if not bool(act.any()):
-                break
-            self.n_iter[act] += 1
+            self.n_iter = self.n_iter + act.long()
             first = act & (self.n_iter == 1)
             upd = act & ~first
-            # ---- direction ------------------------------------------------------------------
-            if bool(first.any()):
-                self.d[first] = -g[first]
-                self.hist[first] = 0
-                self.H_diag[first] = 1.0
-            if bool(upd.any()):
-                y = g - self.prev_g
-                s = self.d * self.t[:, None]
-                ys = (y * s).sum(1)
-                mem = upd & (ys > 1e-10)
-                if bool(mem.any()):
-                    full = mem & (self.hist == self.H)
-                    if bool(full.any()):                                   # limited memory: drop the oldest pair
-                        self.old_dirs[full] = torch.roll(self.old_dirs[full], -1, dims=1)
-                        self.old_stps[full] = torch.roll(self.old_stps[full], -1, dims=1)
-                        self.ro[full] = torch.roll(self.ro[full], -1, dims=1)
-                        self.hist[full] -= 1
-                    rows, pos = idx[mem], self.hist[mem]
-                    self.old_dirs[rows, pos] = y[mem]
-                    self.old_stps[rows, pos] = s[mem]
-                    self.ro[rows, pos] = 1.0 / ys[mem]
-                    self.hist[mem] += 1
-                    self.H_diag[mem] = ys[mem] / (y[mem] * y[mem]).sum(1)
-                # two-loop recursion over the padded history (slots beyond hist[s] are skipped per problem)
-                num_old = int(self.hist[upd].max().item())
-                q = -g
-                al = torch.zeros(S, max(num_old, 1), device=P.device, dtype=P.dtype)
-                for i in range(num_old - 1, -1, -1):
-                    live = (i < self.hist).to(P.dtype)
-                    a = (self.old_stps[:, i] * q).sum(1) * self.ro[:, i] * live
-                    al[:, i] = a
-                    q = q - a[:, None] * self.old_dirs[:, i]
-                r = q * self.H_diag[:, None]
-                for i in range(num_old):
-                    live = (i < self.hist).to(P.dtype)
-                    be = (self.old_dirs[:, i] * r).sum(1) * self.ro[:, i] * live
-                    r = r + self.old_stps[:, i] * ((al[:, i] - be) * live)[:, None]
-                self.d[upd] = r[upd]
-            self.prev_g[act] = g[act]
-            self.prev_loss[act] = loss[act]
-            # ---- step length -----------------------------------------------------------------
+            # ---- curvature memory (torch: "do lbfgs update (update memory)") -------------------
+            self.hist = torch.where(first, torch.zeros_like(self.hist), self.hist)
+            self.head = torch.where(first, torch.zeros_like(self.head), self.head)
+            self.H_diag = torch.where(first, torch.ones_like(self.H_diag), self.H_diag)
+            y = g - self.prev_g
+            s = self.d * self.t[:, None]
+            ys = (y * s).sum(1)
+            mem = upd & (ys > 1e-10)
+            full = mem & (self.hist == self.H)
+            pos = torch.where(full, self.head, (self.head + self.hist) % self.H)      # overwrite the oldest when full
+            m3 = mem[:, None]
+            self.old_dirs[self._rows, pos] = torch.where(m3, y, self.old_dirs[self._rows, pos])
+            self.old_stps[self._rows, pos] = torch.where(m3, s, self.old_stps[self._rows, pos])
+            safe_ys = torch.where(mem, ys, torch.ones_like(ys))
+            self.ro[self._rows, pos] = torch.where(mem, 1.0 / safe_ys, self.ro[self._rows, pos])
+            self.head = torch.where(full, (self.head + one) % self.H, self.head)
+            self.hist = torch.where(mem & ~full, self.hist + one, self.hist)
+            yy = (y * y).sum(1)
+            self.H_diag = torch.where(mem, ys / torch.where(mem, yy, torch.ones_like(yy)), self.H_diag)
+            # ---- direction: empty history gives d = -g, as torch's first iteration -----------------
+            d_new = self._direction(g)
+            self.d = torch.where(act[:, None], d_new, self.d)
+            self.prev_g = torch.where(act[:, None], g, self.prev_g)
+            self.prev_loss = torch.where(act, loss, self.prev_loss)
+            # ---- step length ---------------------------------------------------------------------
             t_first = torch.clamp(1.0 / g.abs().sum(1), max=1.0) * self.lr
-            self.t[act] = torch.where(self.n_iter[act] == 1, t_first[act], torch.full_like(t_first[act], self.lr))
+            t_new = torch.where(self.n_iter == 1, t_first, torch.full_like(t_first, self.lr))
+            self.t = torch.where(act, t_new, self.t)
             gtd = (g * self.d).sum(1)
             act = act & ~(gtd > -self.tol_c)                               # directional derivative below tolerance
-            if not bool(act.any()):
+            P += torch.where(act, self.t, torch.zeros_like(self.t))[:, None] * self.d
+            if it == self.max_iter:                                        # no re-evaluation on the last iteration
                 break
-            P[act] += self.t[act, None] * self.d[act]
-            if it != self.max_iter:                                        # no re-evaluation on the last iteration
-                nl, ng = closure(P)
-                loss[act], g[act] = nl[act], ng[act]
-                stop = (g.abs().amax(1) <= self.tol_g) | ((self.d * self.t[:, None]).abs().amax(1) <= self.tol_c) \
-                    | ((loss - self.prev_loss).abs() < self.tol_c)
-                act = act & ~stop
+            nl, ng = closure(P)
+            loss = torch.where(act, nl, loss)
+            g = torch.where(act[:, None], ng, g)
+            stop = (g.abs().amax(1) <= self.tol_g) | ((self.d * self.t[:, None]).abs().amax(1) <= self.tol_c) \
+                | ((loss - self.prev_loss).abs() < self.tol_c)
+            act = act & ~stop
+            if it % 5 == 0 and not bool(act.any()):                        # the only host sync, every 5th iteration
+                break
         return loss
 
 
@@ -230,18 +245,18 @@ class SeedSweepLBFGS:
         P = P0.clone().contiguous()
         S = P.shape[0]
         self.mask = torch.ones(S, c.d, c.p, device=P.device) if mask0 is None else mask0.clone()
-        opt = BatchedLBFGS(P, self.lr)
+        opt = BatchedLBFGS(P, self.lr, engine=getattr(c, 'engine', None) if P.is_cuda else None)
         prev, pprev = P.clone(), P.clone()
         n_iters = torch.zeros(S, dtype=torch.long, device=P.device)
         done = torch.zeros(S, dtype=torch.bool, device=P.device)
         nan = torch.zeros(S, dtype=torch.bool, device=P.device)
         epochs = torch.zeros(S, dtype=torch.long, device=P.device)
         for epoch in range(num_epochs):
-            live = ~done
-            if not bool(live.any()):
+            if epoch % 4 == 0 and bool(done.all()):                        # host sync every 4th epoch only
                 break
-            n_iters[live] += 1
-            epochs[live] = epoch + 1
+            live = ~done
+            n_iters = n_iters + live.long()
+            epochs = torch.where(live, torch.full_like(epochs, epoch + 1), epochs)
             opt.step(self._closure, frozen=done)
             bad = live & torch.isnan(P).any(dim=1)                         # train.py:697-699
             nan |= bad
@@ -252,15 +267,13 @@ class SeedSweepLBFGS:
             final = conv & (self._norms(P, pprev) < self.tol)             # train.py:709-714
             done |= final
             thr_conv = conv & ~final
-            thr_freq = live & ~conv & (n_iters % self.st_freq == 0) if self.st_freq > 0 else torch.zeros_like(done)
+            thr_freq = (live & ~conv & (n_iters % self.st_freq == 0)) if self.st_freq > 0 else torch.zeros_like(done)
             ev = thr_conv | thr_freq
-            if bool(ev.any()):
-                Xi = self._xi(P)
-                new_mask = torch.logical_and(Xi.abs() > self.threshold, self.mask > 0).float()
-                self.mask[ev] = new_mask[ev]                               # strict >, monotone (sindy.py:194)
-                opt.reset(ev)
-                n_iters[ev] = 0
-                pprev[thr_conv] = P[thr_conv]                              # only on convergence-triggered events (:718)
-            upd_prev = live & ~final
-            prev[upd_prev] = P[upd_prev]
+            Xi = self._xi(P)
+            new_mask = torch.logical_and(Xi.abs() > self.threshold, self.mask > 0).float()
+            self.mask = torch.where(ev[:, None, None], new_mask, self.mask)   # strict >, monotone (sindy.py:194)
+            opt.reset(ev)
+            n_iters = torch.where(ev, torch.zeros_like(n_iters), n_iters)
+            pprev = torch.where(thr_conv[:, None], P, pprev)               # only on convergence-triggered events (:718)
+            prev = torch.where((live & ~final)[:, None], P, prev)
         return {"Xi": self._xi(P), "mask": self.mask, "params": P, "epochs": epochs, "finished": done & ~nan, "nan": nan}

@@ -248,3 +248,24 @@ def test_lbfgs_seed_sweep_on_gpu_matches_sequential_trainer(S, golden, tmp_path,
         assert torch.equal(out["mask"][s], r.mask), s
         want = (r.Xi * r.mask).detach().cpu().numpy()
         assert np.allclose((out["Xi"][s] * out["mask"][s]).cpu().numpy(), want, rtol=5e-3, atol=5e-4), s
+
+
+def test_lbfgs_direction_kernel_matches_torch_recursion(S):
+    """Wave-per-problem two-loop recursion vs the masked torch loops, ring buffers wrapped, ragged history."""
+    from symode_amd.sweep import BatchedLBFGS
+    torch.manual_seed(0)
+    for n, H in [(20, 100), (42, 100), (7, 16), (200, 8)]:
+        Sn = 37
+        P = torch.zeros(Sn, n, device=DEV)
+        a = BatchedLBFGS(P, 1.0, history_size=H, engine=S.get_engine())
+        a.old_dirs.normal_()
+        a.old_stps.normal_()
+        a.ro.uniform_(0.1, 1.0)
+        a.hist = torch.randint(0, H + 1, (Sn,), device=DEV)
+        a.head = torch.randint(0, H, (Sn,), device=DEV)
+        a.H_diag.uniform_(0.5, 2.0)
+        g = torch.randn(Sn, n, device=DEV)
+        got = a._direction(g)
+        a.engine = None
+        want = a._direction(g)
+        assert torch.allclose(got, want, rtol=2e-4, atol=2e-4 * want.abs().max().item()), (n, H)
