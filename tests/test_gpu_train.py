@@ -258,8 +258,8 @@ def test_lbfgs_direction_kernel_matches_torch_recursion(S):
         Sn = 37
         P = torch.zeros(Sn, n, device=DEV)
         a = BatchedLBFGS(P, 1.0, history_size=H, engine=S.get_engine())
-        a.old_dirs.normal_()
-        a.old_stps.normal_()
+        a.old_dirs.normal_().mul_(0.5 / n ** 0.5)            # keep the 2H-step recursion well inside fp32 range
+        a.old_stps.normal_().mul_(0.5 / n ** 0.5)
         a.ro.uniform_(0.1, 1.0)
         a.hist = torch.randint(0, H + 1, (Sn,), device=DEV)
         a.head = torch.randint(0, H, (Sn,), device=DEV)
@@ -268,4 +268,5 @@ def test_lbfgs_direction_kernel_matches_torch_recursion(S):
         got = a._direction(g)
         a.engine = None
         want = a._direction(g)
+        assert torch.isfinite(want).all()
         assert torch.allclose(got, want, rtol=2e-4, atol=2e-4 * want.abs().max().item()), (n, H)
