@@ -88,8 +88,6 @@ def main(argv=None):
                  mse_all=np.mean(mse))
     print(f'{n_seeds} seeds, epochs used {int(out["epochs"].min())}-{int(out["epochs"].max())}, '
           f'finished {int(out["finished"].sum())}, NaN {int(out["nan"].sum())}')
-    import symode_amd.evaluation as ev
-    ev.result_dir = 'eval_results'
     return aggregate_results(args['save_dir'], min_seed=seeds[0], max_seed=seeds[-1] + 1)
 
 
