@@ -137,6 +137,14 @@ int symode_lbfgs_direction(const float* g, const float* old_dirs, const float* o
                            const long* head, const long* count, const float* h_diag, long n_problems, int n,
                            int history, float* d_out, void* stream);
 
+/* HOST function (no GPU work): least squares on the normal equations G = A^T A (n, n), C = A^T b (n, k), fp64
+ * row-major host arrays; A had m_rows rows.  driver 0 = LAPACK gelsy semantics (pivoted QR rank rule with
+ * rcond < 0 -> torch's default eps_fp32 * max(m_rows, n), minimum-norm solution), driver 1 = gels (full rank).
+ * W (n, k) receives the solution, *rank_out the numerical rank.
+ * replaces: torch.linalg.lstsq(A, B) on the ridge-augmented / block-diagonal system, sindy.py:288. */
+int symode_host_lstsq_normal(const double* G, const double* C, int n, int k, long m_rows, int driver, double rcond,
+                             double* W, int* rank_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,7 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_lbfgs_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                        c_int, c_void_p, c_void_p]),
+    "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
 
 ABI_VERSION = 1

@@ -18,6 +18,7 @@ the reference *CPU* path; ``driver='gels'`` gives what the reference computes on
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import numpy as np
@@ -163,8 +164,49 @@ def gelsy_rank(R: np.ndarray, rcond: float) -> int:
     return rank
 
 
-def lstsq_normal(G: np.ndarray, C: np.ndarray, m_rows: int, driver: str = "gelsy", rcond: float | None = None):
+_NATIVE = None
+
+
+def _native():
+    """libsymode_hip.so's host solver (csrc/host_lstsq.cpp), or False when the library is not built."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            from .engine import load_library
+            _NATIVE = load_library()
+        except Exception:
+            _NATIVE = False
+    return _NATIVE
+
+
+def lstsq_normal(G, C, m_rows: int, driver: str = "gelsy", rcond: float | None = None):
     """Solve min ||A w - b|| given G = A^T A (n,n) and C = A^T b (n,k); A had ``m_rows`` rows.
+    Native host routine when libsymode_hip.so is present (same algorithm, ~100x less Python), else
+    the reference implementation below.  Returns (W (n,k) or (n,), rank)."""
+    lib = _native()
+    if not lib:
+        return lstsq_normal_py(G, C, m_rows, driver, rcond)
+    if driver not in ("gelsy", "gels"):
+        raise ValueError(f"unknown lstsq driver {driver!r}")
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    C = np.asarray(C, dtype=np.float64)
+    squeeze = C.ndim == 1
+    C2 = np.ascontiguousarray(C[:, None] if squeeze else C)
+    n, k = G.shape[0], C2.shape[1]
+    W = np.zeros((n, k))
+    rank = ctypes.c_int(0)
+    rc = lib.symode_host_lstsq_normal(G.ctypes.data, C2.ctypes.data, n, k, int(m_rows), 0 if driver == "gelsy" else 1,
+                                      -1.0 if rcond is None else float(rcond), W.ctypes.data, ctypes.addressof(rank))
+    if rc != 0:
+        if driver == "gels":
+            raise np.linalg.LinAlgError("singular normal equations under the full-rank (gels) driver")
+        raise RuntimeError(f"symode_host_lstsq_normal failed with code {rc}")
+    return (W[:, 0] if squeeze else W), rank.value
+
+
+def lstsq_normal_py(G: np.ndarray, C: np.ndarray, m_rows: int, driver: str = "gelsy", rcond: float | None = None):
+    """Pure-numpy reference implementation of ``lstsq_normal`` (kept as the readable specification and
+    for environments without the built library).
 
     Returns (W (n,k), rank).  ``rcond=None`` -> torch's default eps(fp32) * max(m, n).
     """

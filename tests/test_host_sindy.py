@@ -96,12 +96,15 @@ def test_constraint_order5_so2_is_equivariant():
 
 # -------------------------------------------------------------------------- lstsq emulation
 def test_lstsq_normal_matches_torch_gelsy_on_small_problems():
+    """Against LAPACK sgelsy with torch's default rcond, reached through the oracle's scipy wrapper (torch's own
+    CPU wrapper is irreproducible on ill-conditioned systems)."""
+    from oracle.sindy_oracle import lstsq_cpu
     torch.manual_seed(0)
     for n, p, k in [(200, 6, 2), (500, 10, 2), (64, 8, 1)]:
         A = torch.randn(n, p)
         A[:, 3] = A[:, 1] + 1e-3 * torch.randn(n)       # moderately ill-conditioned, still full rank
         B = torch.randn(n, k)
-        lm = torch.linalg.lstsq(A, B)
+        lm = lstsq_cpu(A, B)
         G, C = (A.double().T @ A.double()).numpy(), (A.double().T @ B.double()).numpy()
         W, rank = lstsq.lstsq_normal(G, C, n)
         assert rank == int(lm.rank)
@@ -110,7 +113,7 @@ def test_lstsq_normal_matches_torch_gelsy_on_small_problems():
     A = torch.randn(300, 4)
     A = torch.cat([A, A[:, :1]], dim=1)
     B = torch.randn(300, 1)
-    lm = torch.linalg.lstsq(A, B)
+    lm = lstsq_cpu(A, B)
     W, rank = lstsq.lstsq_normal((A.double().T @ A.double()).numpy(), (A.double().T @ B.double()).numpy(), 300)
     assert rank == int(lm.rank) == 4
     assert np.allclose(W, lm.solution.numpy(), atol=1e-4)
@@ -212,3 +215,27 @@ def test_seed_sweep_matches_per_seed_stlsq(golden):
         assert np.array_equal(mask[s].numpy(), r.mask.numpy())
         assert np.allclose(Xi[s].numpy(), r.Xi.detach().numpy(), rtol=1e-5, atol=1e-6)
     assert len({tuple(sw.idx[s].tolist()) for s in range(5)}) == 5          # every seed has its own subsample
+
+
+def test_native_host_solver_equals_numpy_specification(golden):
+    """csrc/host_lstsq.cpp vs lstsq.lstsq_normal_py: full rank, rank-truncated, rank-deficient, multiple RHS."""
+    rng = np.random.RandomState(1)
+    cases = []
+    for n, k, m in [(6, 2, 300), (10, 2, 2000), (20, 1, 4020), (4, 1, 4020), (12, 3, 125010)]:
+        A = rng.randn(max(3 * n, 40), n)
+        A[:, n // 2] = A[:, 0] * (1 + 1e-3 * rng.randn(A.shape[0]))          # near-collinear pair
+        cases.append((A.T @ A, A.T @ rng.randn(A.shape[0], k), m))
+    g = golden("f5_constraint")
+    cases.append((g["rankdef_G"], g["rankdef_C"], int(g["rankdef_rows"])))
+    dup = rng.randn(50, 5)
+    dup = np.concatenate([dup, dup[:, :2]], axis=1)                           # exactly rank-deficient
+    cases.append((dup.T @ dup, dup.T @ rng.randn(50, 2), 50))
+    assert lstsq._native(), "libsymode_hip.so must be built for this test"
+    for G, C, m in cases:
+        for driver in ("gelsy", "gels"):
+            if driver == "gels" and np.linalg.cond(G) > 1e12:
+                continue                                  # numerically singular: the full-rank driver has no meaningful answer
+            Wp, rp = lstsq.lstsq_normal_py(G, C, m, driver)
+            Wn, rn = lstsq.lstsq_normal(G, C, m, driver)
+            assert rn == rp
+            assert np.allclose(Wn, Wp, rtol=1e-7, atol=1e-9 * np.abs(Wp).max()), (G.shape, driver)
