@@ -23,6 +23,14 @@ const LibOps* find_ops(int d, int order, int flags) {
 
 inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p % a) != 0; }
 
+// Gram passes are MFMA-bound, not latency-bound: at most 256 workgroups per launch keep the number of
+// partials the single finalize block has to add small.
+inline int gram_grid(long n, long S) {
+    const int g = grid_x_for(n, S, 1);
+    const long cap = S >= 256 ? 2 : 256 / S;
+    return g > cap ? (int)cap : g;
+}
+
 // points per 16-byte chunk step (points.hpp, Chunk<D>::PPT)
 inline int ppt_for(int d) { return d == 2 ? 2 : d == 4 ? 1 : 4; }
 
@@ -34,7 +42,7 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
     const size_t nacc = 1 + (size_t)ops->d * ops->p;
     const size_t g_red = (size_t)grid_x_for(n, S, 1);   // widest grid any reduction uses
     const size_t a = (size_t)S * g_red * nacc;
-    const size_t b = (size_t)S * g_red * (BLOCK / WAVE) * gram_partial;
+    const size_t b = (size_t)S * g_red * gram_partial;
     return a > b ? a : b;
 }
 
@@ -126,7 +134,7 @@ int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, in
     if (!x || !dx || !gram_out) return SYMODE_E_NULLPTR;
     if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
-    const int gx = grid_x_for(n, n_problems, 1);
+    const int gx = gram_grid(n, n_problems);
     return (int)ops->aug_gram(x, dx, n_problems, n, nullptr, gram_out, (double*)workspace, gx, (hipStream_t)stream);
 }
 
@@ -138,7 +146,7 @@ int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const in
     if (!x || !dx || !idx || !gram_out) return SYMODE_E_NULLPTR;
     if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(idx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, m);
-    const int gx = grid_x_for(m, n_problems, 1);
+    const int gx = gram_grid(m, n_problems);
     return (int)ops->aug_gram(x, dx, n_problems, m, idx, gram_out, (double*)workspace, gx, (hipStream_t)stream);
 }
 

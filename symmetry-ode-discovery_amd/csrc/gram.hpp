@@ -96,16 +96,27 @@ __global__ __launch_bounds__(BLOCK) void aug_gram_kernel(const float* __restrict
                 }
         }
     }
-    // per-wave partial tiles: element e = row*16 + col of tile pair q at ws[... + q*256 + e];
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
-    double* dst = ws + (((long)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / WAVE) + wave) * G::PARTIAL;
+    // The four waves' tiles are combined in fixed order through LDS (the operand staging area is free now),
+    // so a workgroup leaves ONE partial: element e = row*16 + col of tile pair q at ws[block][q*256 + e].
+    __syncthreads();
+    double* comb = reinterpret_cast<double*>(lds);
+    static_assert(sizeof(lds) >= sizeof(double) * (BLOCK / WAVE) * G::NPAIR * 256, "LDS too small for the wave combine");
 #pragma unroll
     for (int q = 0; q < G::NPAIR; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = (lane >> 4) + 4 * r, col = lane & 15;
-            dst[q * 256 + row * 16 + col] = acc[q][r];
+            comb[(wave * G::NPAIR + q) * 256 + row * 16 + col] = acc[q][r];
         }
+    __syncthreads();
+    double* dst = ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * G::PARTIAL;
+    for (int q = 0; q < G::NPAIR; ++q) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) v += comb[(w * G::NPAIR + q) * 256 + threadIdx.x];
+        dst[q * 256 + threadIdx.x] = v;
+    }
 }
 
 // Sum the n_part per-wave partials of problem s in fixed order and scatter into the dense
@@ -123,7 +134,15 @@ __global__ __launch_bounds__(BLOCK) void gram_finalize_kernel(const double* __re
     for (int ti = 0; ti < T; ++ti)
         for (int tj = ti; tj < T; ++tj, ++q) {
             double v = 0.0;
-            for (int i = 0; i < n_part; ++i) v += src[(long)i * G::PARTIAL + q * 256 + e];
+            int i = 0;
+            for (; i + 8 <= n_part; i += 8) {                  // 8 independent loads in flight, added in fixed order
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = src[(long)(i + u) * G::PARTIAL + q * 256 + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; i < n_part; ++i) v += src[(long)i * G::PARTIAL + q * 256 + e];
             const int R = 16 * ti + row, C = 16 * tj + col;
             if (R < F && C < F) {
                 out[R * F + C] = v;
@@ -137,7 +156,7 @@ hipError_t launch_aug_gram(const float* x, const float* dx, long S, long n, cons
                            int gx, hipStream_t st) {
     aug_gram_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, idx, ws);
     SYMODE_LAUNCH_CHECK();
-    gram_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx * (BLOCK / WAVE), gram);
+    gram_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, gram);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }
