@@ -128,6 +128,20 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
                    int flags, const float* xi, const float* mask, float* grad_x, float* grad_v, float* grad_xi,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Fused K-step Euler flow f and its tangent map: x_out = f(x), t_out = J_f(x) v  for
+ * f = n_steps explicit Euler steps of dx/dt = Theta(x)(xi*mask)^T (all steps in registers).
+ * replaces: forward_step = odeint(regressor, ., int_t, int_dt) and jvp(forward_step, x, v_x)[1] of the
+ * infinitesimal symmetry regulariser, train.py:669-673 + model_utils.py:56. */
+int symode_euler_jvp(const float* x, const float* v, long n, int d, int order, int flags, const float* xi,
+                     const float* mask, int n_steps, float dt, float* x_out, float* t_out, void* stream);
+
+/* Reverse mode of symode_euler_jvp, given g_x = dL/d(x_out), g_t = dL/d(t_out):
+ * grad_x = dL/dx, grad_v = dL/dv (n, d), grad_xi (d, p) masked.  Step states are recomputed from (x, v).
+ * replaces: autograd's double-backward through n_steps regressor calls (model_utils.py:32, 56). */
+int symode_euler_jvp_vjp(const float* x, const float* v, const float* g_x, const float* g_t, long n, int d, int order,
+                         int flags, const float* xi, const float* mask, int n_steps, float dt, float* grad_x,
+                         float* grad_v, float* grad_xi, void* workspace, size_t workspace_bytes, void* stream);
+
 /* L-BFGS search direction d = -H g (two-loop recursion) for n_problems independent problems of n <= 256
  * parameters: curvature pairs in ring buffers old_dirs / old_stps (S, history, n), ro (S, history), with
  * per-problem `head` (oldest slot) and `count` (pairs stored), int64; h_diag (S) scales the initial Hessian.

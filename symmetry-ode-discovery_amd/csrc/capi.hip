@@ -217,4 +217,31 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
                              (hipStream_t)stream);
 }
 
+int symode_euler_jvp(const float* x, const float* v, long n, int d, int order, int flags, const float* xi,
+                     const float* mask, int n_steps, float dt, float* x_out, float* t_out, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 0 || n_steps < 0) return SYMODE_E_BADSIZE;
+    if (n == 0) return SYMODE_OK;
+    if (!x || !v || !xi || !x_out || !t_out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(v, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(x_out, 4) ||
+        misaligned(t_out, 4))
+        return SYMODE_E_ALIGN;
+    return (int)ops->euler_jvp(x, v, n, xi, mask, n_steps, dt, x_out, t_out, (hipStream_t)stream);
+}
+
+int symode_euler_jvp_vjp(const float* x, const float* v, const float* g_x, const float* g_t, long n, int d, int order,
+                         int flags, const float* xi, const float* mask, int n_steps, float dt, float* grad_x,
+                         float* grad_v, float* grad_xi, void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 1 || n_steps < 0) return SYMODE_E_BADSIZE;
+    if (!x || !v || !g_x || !g_t || !xi || !grad_x || !grad_v || !grad_xi) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(v, 4) || misaligned(g_x, 4) || misaligned(g_t, 4) || misaligned(xi, 4) ||
+        misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
+        return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(1, n);
+    const int gx = grid_x_for(n, 1, 1);
+    return (int)ops->euler_jvp_vjp(x, v, g_x, g_t, n, xi, mask, n_steps, dt, grad_x, grad_v, grad_xi,
+                                   (double*)workspace, gx, (hipStream_t)stream);
+}
+
 }  // extern "C"

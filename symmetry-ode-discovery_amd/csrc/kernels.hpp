@@ -45,6 +45,11 @@ struct LibOps {
     hipError_t (*jvp_vjp)(const float* x, const float* v, const float* g_out, const float* g_jv, long n, const float* xi,
                           const float* mask, float* grad_x, float* grad_v, float* grad_xi, double* ws, int gx,
                           hipStream_t st);
+    hipError_t (*euler_jvp)(const float* x, const float* v, long n, const float* xi, const float* mask, int n_steps,
+                            float dt, float* x_out, float* t_out, hipStream_t st);
+    hipError_t (*euler_jvp_vjp)(const float* x, const float* v, const float* g_x, const float* g_t, long n, const float* xi,
+                                const float* mask, int n_steps, float dt, float* grad_x, float* grad_v, float* grad_xi,
+                                double* ws, int gx, hipStream_t st);
 };
 
 // ---------------------------------------------------------------------------------------
@@ -668,6 +673,106 @@ __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused K-step Euler flow with its tangent map (the `f` of the infinitesimal regulariser S2):
+//   x_{k+1} = x_k + dt h(x_k),   t_{k+1} = t_k + dt J_h(x_k) t_k,   h = Theta(.) Xi_m^T
+// forward: (x_K, t_K) = (f(x_0), J_f(x_0) t_0) with all K steps in registers;
+// reverse: adjoints (a_x, a_t) walk the steps backwards; step k's state is recomputed from (x_0, t_0)
+//          (K(K-1)/2 cheap library evaluations instead of K state vectors per thread).
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__device__ __forceinline__ void euler_tangent_steps(const float (&w)[Lib::D * Lib::P], float (&x)[Lib::D],
+                                                    float (&t)[Lib::D], int n_steps, float dt) {
+    constexpr int D = Lib::D, P = Lib::P;
+    for (int s = 0; s < n_steps; ++s) {
+        float th[P], dth[P], h[D], jt[D];
+        Lib::eval_jvp(x, t, th, dth);
+        apply_xi<Lib>(w, th, h);
+        apply_xi<Lib>(w, dth, jt);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            x[j] = x[j] + dt * h[j];
+            t[j] = t[j] + dt * jt[j];
+        }
+    }
+}
+
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void euler_jvp_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                          long N, const float* __restrict__ xi,
+                                                          const float* __restrict__ mask, int n_steps, float dt,
+                                                          float* __restrict__ x_out, float* __restrict__ t_out) {
+    constexpr int D = Lib::D;
+    float w[D * Lib::P];
+    load_xi<Lib>(xi, mask, 0, w);
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    for (long n = tid; n < N; n += nthreads) {
+        float xp[D], tp[D];
+        load_point<D>(x, n, xp);
+        load_point<D>(v, n, tp);
+        euler_tangent_steps<Lib>(w, xp, tp, n_steps, dt);
+        store_point<D>(x_out, n, xp);
+        store_point<D>(t_out, n, tp);
+    }
+}
+
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                              const float* __restrict__ g_x,
+                                                              const float* __restrict__ g_t, long N,
+                                                              const float* __restrict__ xi,
+                                                              const float* __restrict__ mask, int n_steps, float dt,
+                                                              float* __restrict__ grad_x, float* __restrict__ grad_v,
+                                                              double* __restrict__ ws) {
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, 0, w);
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    for (long n = tid; n < N; n += nthreads) {
+        float x0[D], t0[D], ax[D], at[D];
+        load_point<D>(x, n, x0);
+        load_point<D>(v, n, t0);
+        load_point<D>(g_x, n, ax);
+        load_point<D>(g_t, n, at);
+        for (int k = n_steps - 1; k >= 0; --k) {
+            float xk[D], tk[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                xk[j] = x0[j];
+                tk[j] = t0[j];
+            }
+            euler_tangent_steps<Lib>(w, xk, tk, k, dt);               // state entering step k
+            float th[P], dth[P], bar[P], dbar[P], bx[D], bv[D];
+            Lib::eval_jvp(xk, tk, th, dth);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                float a = 0.0f, c = 0.0f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const float go = dt * ax[j], gt = dt * at[j];   // adjoints on h(x_k) and on J_h(x_k) t_k
+                    a = fmaf(go, w[j * P + q], a);
+                    c = fmaf(gt, w[j * P + q], c);
+                    acc[1 + j * P + q] = fmaf(go, th[q], fmaf(gt, dth[q], acc[1 + j * P + q]));
+                }
+                bar[q] = a;
+                dbar[q] = c;
+            }
+            Lib::vjp_of_jvp(xk, tk, th, dth, bar, dbar, bx, bv);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                ax[j] += bx[j];
+                at[j] += bv[j];
+            }
+        }
+        store_point<D>(grad_x, n, ax);
+        store_point<D>(grad_v, n, at);
+    }
+    emit_partials<NACC>(acc, ws);
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 #define SYMODE_LAUNCH_CHECK() \
@@ -784,6 +889,29 @@ hipError_t launch_jvp_vjp(const float* x, const float* v, const float* g_out, co
                           hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
     jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, ws);
+    SYMODE_LAUNCH_CHECK();
+    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_euler_jvp(const float* x, const float* v, long n, const float* xi, const float* mask, int n_steps,
+                            float dt, float* x_out, float* t_out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const int g = grid_x_for(n, 1, 1);
+    euler_jvp_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, v, n, xi, mask, n_steps, dt, x_out, t_out);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_euler_jvp_vjp(const float* x, const float* v, const float* g_x, const float* g_t, long n,
+                                const float* xi, const float* mask, int n_steps, float dt, float* grad_x, float* grad_v,
+                                float* grad_xi, double* ws, int gx, hipStream_t st) {
+    constexpr int NACC = 1 + Lib::D * Lib::P;
+    euler_jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_x, g_t, n, xi, mask, n_steps, dt, grad_x,
+                                                                  grad_v, ws);
     SYMODE_LAUNCH_CHECK();
     finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
     SYMODE_LAUNCH_CHECK();

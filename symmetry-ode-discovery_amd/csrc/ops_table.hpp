@@ -21,7 +21,9 @@ constexpr LibOps make_ops() {
                   &launch_aug_gram<Lib>,
                   &launch_vjp<Lib>,
                   &launch_forward_jvp<Lib>,
-                  &launch_jvp_vjp<Lib>};
+                  &launch_jvp_vjp<Lib>,
+                  &launch_euler_jvp<Lib>,
+                  &launch_euler_jvp_vjp<Lib>};
 }
 
 #define SYMODE_OPS_ALL_FLAGS(D, O) make_ops<D, O, 0>(), make_ops<D, O, 1>(), make_ops<D, O, 2>(), make_ops<D, O, 3>()

@@ -45,6 +45,10 @@ _SIGNATURES = {
                                    c_void_p, c_void_p]),
     "symode_jvp_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_euler_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p,
+                                 c_void_p, c_void_p]),
+    "symode_euler_jvp_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_lbfgs_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                        c_int, c_void_p, c_void_p]),
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
@@ -305,6 +309,37 @@ class HipEngine:
                     "symode_jvp_vjp")
         return gx, gv, gxi
 
+
+    def euler_jvp(self, x, v, xi, mask, order, flags, n_steps, dt):
+        """(f(x), J_f(x) v) for f = n_steps Euler steps of the regressor ODE; one launch."""
+        x, v = self._dev(x, "x"), self._dev(v, "v")
+        d = x.shape[-1]
+        n = x.numel() // d
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        self._check_coef(xi, mask, d, order, flags)
+        xo, to = torch.empty_like(x), torch.empty_like(x)
+        self._check(self.lib.symode_euler_jvp(self._ptr(x), self._ptr(v), n, d, order, flags, self._ptr(xi), self._ptr(mask),
+                                              int(n_steps), float(dt), self._ptr(xo), self._ptr(to), self._stream(x)),
+                    "symode_euler_jvp")
+        return xo, to
+
+    def euler_jvp_vjp(self, x, v, g_x, g_t, xi, mask, order, flags, n_steps, dt):
+        """Reverse mode of euler_jvp: (grad_x, grad_v, grad_xi)."""
+        x, v, g_x, g_t = (self._dev(a, nm) for a, nm in ((x, "x"), (v, "v"), (g_x, "g_x"), (g_t, "g_t")))
+        d = x.shape[-1]
+        n = x.numel() // d
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        p = self._check_coef(xi, mask, d, order, flags)
+        gx, gv = torch.empty_like(x), torch.empty_like(x)
+        gxi = torch.empty(d, p, dtype=torch.float32, device=x.device)
+        ws = self.workspace(x.device, d, order, flags, 1, n)
+        self._check(self.lib.symode_euler_jvp_vjp(self._ptr(x), self._ptr(v), self._ptr(g_x), self._ptr(g_t), n, d, order,
+                                                  flags, self._ptr(xi), self._ptr(mask), int(n_steps), float(dt),
+                                                  self._ptr(gx), self._ptr(gv), self._ptr(gxi), self._ptr(ws),
+                                                  ws.numel() * 8, self._stream(x)), "symode_euler_jvp_vjp")
+        return gx, gv, gxi
 
     def lbfgs_direction(self, g, old_dirs, old_stps, ro, head, count, h_diag):
         """d = -H g by the two-loop recursion for S problems at once (ring-buffered curvature pairs)."""

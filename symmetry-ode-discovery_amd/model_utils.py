@@ -55,6 +55,25 @@ def odeint(f, x0, t, dt, method='euler', full_traj=False):
     return torch.stack(traj, dim=0) if full_traj else x0
 
 
+class _EulerFlowFn(torch.autograd.Function):
+    """(f(x), J_f(x) v) for f = K Euler steps of the regressor ODE: ONE fused launch forward, one backward
+    (symode_euler_jvp / symode_euler_jvp_vjp), differentiable once w.r.t. x, v and Xi."""
+
+    @staticmethod
+    def forward(ctx, x, v, xi, mask, reg, n_steps, dt):
+        ctx.reg, ctx.n_steps, ctx.dt = reg, n_steps, dt
+        ctx.save_for_backward(x, v, xi, mask)
+        return reg.engine.euler_jvp(x.detach(), v.detach(), xi.detach(), mask, reg.poly_order, reg.flags, n_steps, dt)
+
+    @staticmethod
+    def backward(ctx, g_x, g_t):
+        x, v, xi, mask = ctx.saved_tensors
+        reg = ctx.reg
+        gx, gv, gxi = reg.engine.euler_jvp_vjp(x.detach(), v.detach(), g_x.contiguous(), g_t.contiguous(), xi.detach(), mask,
+                                               reg.poly_order, reg.flags, ctx.n_steps, ctx.dt)
+        return gx, gv, gxi, None, None, None, None
+
+
 class _EulerFlow:
     """f = odeint(regressor, ., int_t, int_dt) together with its tangent map.
 
@@ -66,12 +85,29 @@ class _EulerFlow:
     def __init__(self, regressor, int_t, int_dt, method='euler'):
         self.regressor, self.int_t, self.int_dt, self.method = regressor, int_t, int_dt, method
 
+    def _fused(self, x):
+        reg = self.regressor
+        return (self.method == 'euler' and isinstance(reg, SINDyRegression) and x.is_cuda
+                and hasattr(reg.engine, 'euler_jvp'))
+
     def __call__(self, x):
+        if self._fused(x) and torch.is_grad_enabled():
+            reg = self.regressor
+            lead = x.shape[:-1]
+            x2 = x.reshape(-1, reg.latent_dim)
+            out, _ = _EulerFlowFn.apply(x2, torch.zeros_like(x2), reg.get_Xi(), reg.mask, reg,
+                                        int(self.int_t / self.int_dt), self.int_dt)
+            return out.reshape(*lead, reg.latent_dim)
         return odeint(self.regressor, x, self.int_t, self.int_dt, self.method)
 
     def tangent(self, x, v):
         n_steps = int(self.int_t / self.int_dt)
         reg, dt = self.regressor, self.int_dt
+        if self._fused(x):
+            lead = x.shape[:-1]
+            xo, to = _EulerFlowFn.apply(x.reshape(-1, reg.latent_dim), v.reshape(-1, reg.latent_dim), reg.get_Xi(), reg.mask,
+                                        reg, n_steps, dt)
+            return xo.reshape(*lead, reg.latent_dim), to.reshape(*lead, reg.latent_dim)
         for _ in range(n_steps):
             if self.method != 'euler':
                 raise NotImplementedError('tangent flow is implemented for the Euler integrator')

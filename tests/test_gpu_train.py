@@ -270,3 +270,34 @@ def test_lbfgs_direction_kernel_matches_torch_recursion(S):
         want = a._direction(g)
         assert torch.isfinite(want).all()
         assert torch.allclose(got, want, rtol=2e-4, atol=2e-4 * want.abs().max().item()), (n, H)
+
+
+def test_fused_euler_flow_matches_stepwise_tangent_flow_and_its_gradients(S):
+    """symode_euler_jvp / _vjp (K steps in one launch) vs the step-by-step route (forward_and_jvp per step)."""
+    from symode_amd import model_utils as MU
+    torch.manual_seed(9)
+    for d, order, sine, exp, K in [(2, 3, False, False, 10), (2, 2, False, True, 3), (3, 2, True, False, 5), (2, 5, False, False, 4)]:
+        r = S.SINDyRegression(d, order, sine, exp, threshold=0.1, device=DEV)
+        r.Xi.data *= 0.3
+        r.mask = (torch.rand_like(r.mask) > 0.2).float()
+        x, v = (torch.randn(400, d) * 0.5).to(DEV), torch.randn(400, d).to(DEV)
+        c1, c2 = torch.randn(400, d).to(DEV), torch.randn(400, d).to(DEV)
+        dt = 0.01
+        flow = MU._EulerFlow(r, K * dt + 1e-9, dt)
+        out = []
+        for fused in (True, False):
+            xg, vg = x.clone().requires_grad_(True), v.clone().requires_grad_(True)
+            r.Xi.grad = None
+            if fused:
+                fx, tv = flow.tangent(xg, vg)
+            else:
+                fx, tv = xg, vg
+                for _ in range(K):
+                    h, jv = r.forward_and_jvp(fx, tv)
+                    fx, tv = fx + dt * h, tv + dt * jv
+            ((fx * c1).sum() + (tv * c2).sum()).backward()
+            out.append([t_.detach().cpu() for t_ in (fx, tv, xg.grad, vg.grad, r.Xi.grad)])
+        for a, b, nm in zip(out[0], out[1], ["f(x)", "J_f v", "dx", "dv", "dXi"]):
+            assert torch.allclose(a, b, rtol=2e-4, atol=2e-5 * max(b.abs().max().item(), 1e-6)), (d, order, nm)
+        with torch.no_grad():
+            assert torch.allclose(flow(x), out[0][0].to(DEV), rtol=1e-5, atol=1e-6)     # odeint kernel == fused flow
