@@ -218,6 +218,8 @@ class HipEngine:
             raise SymodeError("aug_gram_gather expects x, dx (N, d) and idx (S, M)")
         n_src, d = x.shape
         S, m = idx.shape
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_src):       # the kernel trusts the table
+            raise SymodeError("idx holds row indices outside [0, N)")
         p = self.lib_size(d, order, flags)
         gram = torch.empty(S, p + d, p + d, dtype=torch.float64, device=x.device)
         ws = self.workspace(x.device, d, order, flags, S, m)
