@@ -128,6 +128,14 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
                    int flags, const float* xi, const float* mask, float* grad_x, float* grad_v, float* grad_xi,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Offline data generation: n_traj RK4 orbits of dx/dt = Theta(x) xi^T (xi (d, p) fp64, unmasked) from x0
+ * (n_traj, d) fp64, n_steps of size dt; every `subsample`-th state and its exact derivative are written as
+ * fp32 x_out, dx_out (n_traj, ceil(n_steps/subsample), d).  One trajectory per thread, fp64 arithmetic.
+ * replaces: solve_ode_batch + the subsample/transposes of gen_data, data_utils/ode.py:7-28, 45-48, for systems
+ * the library can express (all four shipped ones: evaluation/eval_eq.py:88-105). */
+int symode_rk4_traj(const double* x0, long n_traj, int d, int order, int flags, const double* xi, int n_steps, double dt,
+                    int subsample, float* x_out, float* dx_out, void* stream);
+
 /* Fused K-step Euler flow f and its tangent map: x_out = f(x), t_out = J_f(x) v  for
  * f = n_steps explicit Euler steps of dx/dt = Theta(x)(xi*mask)^T (all steps in registers).
  * replaces: forward_step = odeint(regressor, ., int_t, int_dt) and jvp(forward_step, x, v_x)[1] of the

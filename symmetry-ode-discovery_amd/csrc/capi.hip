@@ -217,6 +217,16 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
                              (hipStream_t)stream);
 }
 
+int symode_rk4_traj(const double* x0, long n_traj, int d, int order, int flags, const double* xi, int n_steps, double dt,
+                    int subsample, float* x_out, float* dx_out, void* stream) {
+    SYMODE_GET_OPS();
+    if (n_traj < 0 || n_steps < 1 || subsample < 1) return SYMODE_E_BADSIZE;
+    if (n_traj == 0) return SYMODE_OK;
+    if (!x0 || !xi || !x_out || !dx_out) return SYMODE_E_NULLPTR;
+    if (misaligned(x0, 8) || misaligned(xi, 8) || misaligned(x_out, 4) || misaligned(dx_out, 4)) return SYMODE_E_ALIGN;
+    return (int)ops->rk4_traj(x0, n_traj, xi, n_steps, dt, subsample, x_out, dx_out, (hipStream_t)stream);
+}
+
 int symode_euler_jvp(const float* x, const float* v, long n, int d, int order, int flags, const float* xi,
                      const float* mask, int n_steps, float dt, float* x_out, float* t_out, void* stream) {
     SYMODE_GET_OPS();

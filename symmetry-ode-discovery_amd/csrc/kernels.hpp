@@ -45,6 +45,8 @@ struct LibOps {
     hipError_t (*jvp_vjp)(const float* x, const float* v, const float* g_out, const float* g_jv, long n, const float* xi,
                           const float* mask, float* grad_x, float* grad_v, float* grad_xi, double* ws, int gx,
                           hipStream_t st);
+    hipError_t (*rk4_traj)(const double* x0, long n_traj, const double* xi, int n_steps, double dt, int subsample,
+                           float* x_out, float* dx_out, hipStream_t st);
     hipError_t (*euler_jvp)(const float* x, const float* v, long n, const float* xi, const float* mask, int n_steps,
                             float dt, float* x_out, float* t_out, hipStream_t st);
     hipError_t (*euler_jvp_vjp)(const float* x, const float* v, const float* g_x, const float* g_t, long n, const float* xi,
@@ -673,6 +675,63 @@ __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// Offline data generation (reference data_utils/ode.py:7-28, 45-48): fixed-step RK4 orbits of
+// dx/dt = Theta(x) Xi^T in fp64, one trajectory per thread, every `subsample`-th state and its exact
+// derivative written as fp32 (n_traj, n_out, D).  Not part of the timed path.
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void rk4_traj_kernel(const double* __restrict__ x0, long n_traj,
+                                                         const double* __restrict__ xi, int n_steps, double dt,
+                                                         int subsample, float* __restrict__ x_out,
+                                                         float* __restrict__ dx_out) {
+    constexpr int D = Lib::D, P = Lib::P;
+    const long tr = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (tr >= n_traj) return;
+    double w[D * P];
+#pragma unroll
+    for (int i = 0; i < D * P; ++i) w[i] = xi[i];
+    auto f = [&](const double (&y)[D], double (&h)[D]) {
+        double th[P];
+        Lib::eval_f64(y, th);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) s = fma(w[j * P + k], th[k], s);
+            h[j] = s;
+        }
+    };
+    double x[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = x0[tr * D + j];
+    const long n_out = (n_steps + subsample - 1) / subsample;
+    for (int i = 0; i < n_steps; ++i) {
+        double d1[D], d2[D], d3[D], d4[D], y[D];
+        f(x, d1);
+        if (i % subsample == 0) {
+            const long o = (tr * n_out + i / subsample) * D;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                x_out[o + j] = (float)x[j];
+                dx_out[o + j] = (float)d1[j];
+            }
+        }
+        if (i == n_steps - 1) break;
+#pragma unroll
+        for (int j = 0; j < D; ++j) y[j] = x[j] + 0.5 * (dt * d1[j]);
+        f(y, d2);
+#pragma unroll
+        for (int j = 0; j < D; ++j) y[j] = x[j] + 0.5 * (dt * d2[j]);
+        f(y, d3);
+#pragma unroll
+        for (int j = 0; j < D; ++j) y[j] = x[j] + dt * d3[j];
+        f(y, d4);
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = x[j] + (dt * d1[j] + 2 * (dt * d2[j]) + 2 * (dt * d3[j]) + dt * d4[j]) / 6;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Fused K-step Euler flow with its tangent map (the `f` of the infinitesimal regulariser S2):
 //   x_{k+1} = x_k + dt h(x_k),   t_{k+1} = t_k + dt J_h(x_k) t_k,   h = Theta(.) Xi_m^T
 // forward: (x_K, t_K) = (f(x_0), J_f(x_0) t_0) with all K steps in registers;
@@ -914,6 +973,16 @@ hipError_t launch_euler_jvp_vjp(const float* x, const float* v, const float* g_x
                                                                   grad_v, ws);
     SYMODE_LAUNCH_CHECK();
     finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_rk4_traj(const double* x0, long n_traj, const double* xi, int n_steps, double dt, int subsample,
+                           float* x_out, float* dx_out, hipStream_t st) {
+    if (n_traj == 0) return hipSuccess;
+    const unsigned g = (unsigned)((n_traj + BLOCK - 1) / BLOCK);
+    rk4_traj_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x0, n_traj, xi, n_steps, dt, subsample, x_out, dx_out);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }

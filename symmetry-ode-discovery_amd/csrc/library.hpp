@@ -86,6 +86,21 @@ struct Library {
         }
     }
 
+    // Same recurrence in fp64 (offline data generation only: the reference integrates in numpy float64).
+    static __device__ __forceinline__ void eval_f64(const double (&x)[D], double (&th)[P]) {
+        th[0] = 1.0;
+#pragma unroll
+        for (int t = 1; t < NP; ++t) th[t] = th[tab.parent[t]] * x[tab.var[t]];
+        if constexpr (SINE) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) th[SIN0 + i] = sin(x[i]);
+        }
+        if constexpr (EXP) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) th[EXP0 + i] = exp(x[i]);
+        }
+    }
+
     // Theta(x) and the directional derivative dth = J_Theta(x) . v  (product rule along the
     // same recurrence: d(th_q * x_v) = dth_q * x_v + th_q * v_v).
     static __device__ __forceinline__ void eval_jvp(const float (&x)[D], const float (&v)[D], float (&th)[P],

@@ -22,6 +22,7 @@ constexpr LibOps make_ops() {
                   &launch_vjp<Lib>,
                   &launch_forward_jvp<Lib>,
                   &launch_jvp_vjp<Lib>,
+                  &launch_rk4_traj<Lib>,
                   &launch_euler_jvp<Lib>,
                   &launch_euler_jvp_vjp<Lib>};
 }

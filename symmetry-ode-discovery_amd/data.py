@@ -81,15 +81,39 @@ def rk4_trajectories(rhs, x0, dt, num_steps):
     return x.transpose(0, 1).contiguous(), dx.transpose(0, 1).contiguous()
 
 
-def make_dataset(name, n_ics, num_steps, dt=None, noise=0.0, seed=0, device="cpu", n_problems=1):
+# The four systems as library coefficients (evaluation/eval_eq.py:88-105): (poly_order, include_exp, Xi)
+_LIBRARY_FORM = {
+    "dosc": (2, False, [[0.0, -0.1, -1, 0.0, 0.0, 0.0], [0.0, 1, -0.1, 0.0, 0.0, 0.0]]),
+    "growth": (2, False, [[0.0, -0.3, 0.0, 0.0, 0.0, 0.1], [0.0, 0.0, 1.0, 0.0, 0.0, 0.0]]),
+    "selkov": (3, False, [[0.75, -0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0], [0.0, 0.1, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]]),
+    "lv": (2, True, [[2 / 3, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -4 / 3], [-1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]]),
+}
+
+
+def rk4_trajectories_fused(name, x0, dt, num_steps, subsample=1):
+    """Same orbits from ONE HIP launch (symode_rk4_traj: a trajectory per thread, fp64), fp32 output."""
+    from .engine import get_engine
+    order, use_exp, xi = _LIBRARY_FORM[name]
+    xi = torch.tensor(xi, dtype=torch.float64, device=x0.device)
+    return get_engine().rk4_traj(x0, xi, order, 2 if use_exp else 0, num_steps, dt, subsample)
+
+
+def make_dataset(name, n_ics, num_steps, dt=None, noise=0.0, seed=0, device="cpu", n_problems=1, fused=None):
     """fp32 (n_problems, n_ics*num_steps, d) trajectories and derivatives, flattened like ODEDataset
-    (dataset.py:193-194).  Every problem gets its own initial conditions and noise draw."""
+    (dataset.py:193-194).  Every problem gets its own initial conditions and noise draw.
+    ``fused`` (default: on for CUDA devices) integrates with the HIP RK4 kernel instead of torch ops."""
     rhs, ics, dt0 = SYSTEMS[name]
     dt = dt0 if dt is None else dt
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     x0 = ics(n_problems * n_ics, gen, device)
-    x, dx = rk4_trajectories(rhs, x0, dt, num_steps)
+    if fused is None:
+        fused = torch.device(device).type == "cuda"
+    if fused:
+        x, dx = rk4_trajectories_fused(name, x0, dt, num_steps)
+        x, dx = x.double(), dx
+    else:
+        x, dx = rk4_trajectories(rhs, x0, dt, num_steps)
     d = x.shape[-1]
     x = x.reshape(n_problems, n_ics * num_steps, d)
     dx = dx.reshape(n_problems, n_ics * num_steps, d)

@@ -45,6 +45,8 @@ _SIGNATURES = {
                                    c_void_p, c_void_p]),
     "symode_jvp_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_rk4_traj": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_int, ctypes.c_double, c_int, c_void_p, c_void_p,
+                                c_void_p]),
     "symode_euler_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                  c_void_p, c_void_p]),
     "symode_euler_jvp_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -311,6 +313,21 @@ class HipEngine:
                     "symode_jvp_vjp")
         return gx, gv, gxi
 
+
+    def rk4_traj(self, x0, xi, order, flags, n_steps, dt, subsample=1):
+        """fp32 (x, dx) of shape (n_traj, ceil(n_steps/subsample), d): fp64 RK4 orbits of dx/dt = Theta(x) xi^T."""
+        x0 = self._dev(x0, "x0", torch.float64)
+        xi = self._dev(xi, "xi", torch.float64)
+        n_traj, d = x0.shape
+        p = self.lib_size(d, order, flags)
+        if xi.shape != (d, p):
+            raise SymodeError(f"xi must be ({d}, {p}), got {tuple(xi.shape)}")
+        n_out = (n_steps + subsample - 1) // subsample
+        x = torch.empty(n_traj, n_out, d, dtype=torch.float32, device=x0.device)
+        dx = torch.empty_like(x)
+        self._check(self.lib.symode_rk4_traj(self._ptr(x0), n_traj, d, order, flags, self._ptr(xi), int(n_steps), float(dt),
+                                             int(subsample), self._ptr(x), self._ptr(dx), self._stream(x0)), "symode_rk4_traj")
+        return x, dx
 
     def euler_jvp(self, x, v, xi, mask, order, flags, n_steps, dt):
         """(f(x), J_f(x) v) for f = n_steps Euler steps of the regressor ODE; one launch."""
