@@ -24,7 +24,7 @@ def lib():
 def declared_symbols():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(symode_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(symode_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
