@@ -303,12 +303,13 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 // non-temporal loads (default).  Measured on MI355X, S=1024 x 125000 points, d=2 (round 1):
 //   order 5: 0 -> 4.8 TB/s, 4 -> 5.3 TB/s;  order 3: 0 -> 5.6 TB/s, 4 -> 6.3 TB/s (alg. bytes).
 // A software-prefetch form (next chunk loaded before computing the current one) and forms with
-// sched_barrier between points were slower or equal; -fno-slp-vectorize (Makefile) is worth
+// sched_barrier between points were slower or equal; forcing 5-6 waves/SIMD (amdgpu_waves_per_eu) spills at
+// order 5 (8-11x slower) and 4 waves is within 1.3 % of the free allocation; -fno-slp-vectorize (Makefile) is worth
 // 6 % at order 5: packed fp32 FMAs force the uniform coefficients out of SGPRs into VGPR pairs.
 template <class Lib, int VARIANT>
-__global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
-                                                          long N, bool vec, const float* __restrict__ xi,
-                                                          const float* __restrict__ mask, double* __restrict__ ws) {
+__device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, const float* __restrict__ dx, long N, bool vec,
+                                               const float* __restrict__ xi, const float* __restrict__ mask,
+                                               double* __restrict__ ws) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
     constexpr bool NT = (VARIANT == 4);
     const long s = blockIdx.y;
@@ -430,6 +431,13 @@ __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restric
         for (long n = tid; n < N; n += nthreads) point(n);
     }
     emit_partials<NACC>(acc, ws);
+}
+
+template <class Lib, int VARIANT>
+__global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
+                                                          long N, bool vec, const float* __restrict__ xi,
+                                                          const float* __restrict__ mask, double* __restrict__ ws) {
+    loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws);
 }
 
 // ---------------------------------------------------------------------------------------
