@@ -70,6 +70,7 @@ inline int grid_x_for(long n, long S, int pts_per_thread_iter) {
     }
     long cap = max_grid_x() / (S < 1 ? 1 : S);
     if (cap < 2) cap = 2;
+    if (cap > 2048) cap = 2048;        // one finalize block per problem adds the partial rows: keep them few
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;

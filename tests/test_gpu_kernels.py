@@ -271,3 +271,21 @@ def test_rk4_trajectory_kernel_matches_fp64_reference_integrator(eng, name):
     a, b = data.make_dataset(name, 4, 300, seed=5, device="cuda", fused=True)
     c, d_ = data.make_dataset(name, 4, 300, seed=5, device="cuda", fused=False)
     assert torch.allclose(a, c, rtol=2e-6, atol=1e-7) and torch.allclose(b, d_, rtol=2e-6, atol=1e-7)
+
+
+def test_roofline_shape_2_27_points_single_problem(eng):
+    """SURVEY H1 shape: one problem of N = 2^27 points (2 GiB of x + dx, far beyond the 256 MiB Infinity Cache).
+    Size-independent property: loss and gradient equal the quadratic forms of the fp64 Gram of the same data."""
+    N, d, order, p = 1 << 27, 2, 3, 10
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(N, d, device="cuda", generator=g) * 0.6
+    dx = torch.randn(N, d, device="cuda", generator=g)
+    Xi = (torch.randn(d, p, generator=torch.Generator().manual_seed(1)) * 0.3).cuda()
+    loss, grad = eng.loss_grad(x, dx, Xi, None, order)
+    G = eng.aug_gram(x, dx, order)
+    W = Xi.double()
+    want_loss = (torch.trace(W @ G[:p, :p] @ W.T) - 2 * torch.trace(W @ G[:p, p:]) + torch.trace(G[p:, p:])) / (N * d)
+    want_grad = 2.0 / (N * d) * (W @ G[:p, :p] - G[:p, p:].T)
+    assert np.isclose(loss.item(), want_loss.item(), rtol=2e-5)
+    assert_close_scaled(grad.cpu().numpy(), want_grad.cpu().numpy(), 2e-5)
+    assert abs(G[0, 0].item() - N) < 0.5                      # the constant column counts the points exactly
