@@ -310,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 template <class Lib, int VARIANT>
 __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, const float* __restrict__ dx, long N, bool vec,
                                                const float* __restrict__ xi, const float* __restrict__ mask,
-                                               double* __restrict__ ws) {
+                                               double* __restrict__ ws, const bool SEGMENTED) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
     constexpr bool NT = (VARIANT == 4);
     const long s = blockIdx.y;
@@ -351,10 +351,19 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
     };
 
     const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
-    const long nthreads = (long)gridDim.x * BLOCK;
+    long nthreads = (long)gridDim.x * BLOCK;
     if (vec) {
-        const long nchunks = N / PPT;
+        const long nchunks_all = N / PPT;
+        long nchunks = nchunks_all;
         long c = tid;
+        if (SEGMENTED) {
+            // every workgroup streams its own contiguous slab of the problem (as the batched launches do)
+            const long per = (nchunks_all + gridDim.x - 1) / gridDim.x;
+            const long lo = (long)blockIdx.x * per;
+            nchunks = lo + per < nchunks_all ? lo + per : nchunks_all;
+            c = lo + threadIdx.x;
+            nthreads = BLOCK;
+        }
         if constexpr (VARIANT == 2 || VARIANT == 4) {
             for (; c + nthreads < nchunks; c += 2 * nthreads) {
                 float4 ax[NV], ay[NV], bx[NV], by[NV];
@@ -393,7 +402,7 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
                         (__attribute__((address_space(3))) void*)&ring[st][NV + i][wbase], 16, 0, 0);
                 }
             };
-            const long c0 = (long)blockIdx.x * BLOCK;            // block-uniform trip count
+            const long c0 = c - threadIdx.x;                     // block-uniform trip count (first chunk of this workgroup)
             const long iters = nchunks > c0 ? (nchunks - c0 + nthreads - 1) / nthreads : 0;
             if (iters > 0 && nchunks > 0) {
 #pragma unroll
@@ -426,7 +435,7 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
                 chunk(ax, ay);
             }
         }
-        const long n = nchunks * PPT + tid;
+        const long n = nchunks_all * PPT + tid;
         if (n < N) point(n);
     } else {
         for (long n = tid; n < N; n += nthreads) point(n);
@@ -437,8 +446,9 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
 template <class Lib, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                           long N, bool vec, const float* __restrict__ xi,
-                                                          const float* __restrict__ mask, double* __restrict__ ws) {
-    loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws);
+                                                          const float* __restrict__ mask, double* __restrict__ ws,
+                                                          bool segmented) {
+    loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws, segmented);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -892,12 +902,24 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
                             float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
     const bool vec = vec_ok(x, n, Lib::D, S) && vec_ok(dx, n, Lib::D, S);
+    // A single large problem runs as ONE balanced round of resident workgroups (grid-stride inside):
+    // 2048 blocks over 768 resident slots (order 5) left a 2/3-empty last round (-20 % at N = 2^27).
+    static const int resident = [] {
+        int nb = 0, cu = 256, dev = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, 4>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+        return nb * cu;
+    }();
+    if (S == 1 && gx > resident) gx = resident;
+    static const int seg_env = getenv("SYMODE_SEGMENTED") ? atoi(getenv("SYMODE_SEGMENTED")) : 1;
+    // contiguous slab per workgroup: 1 = for one big problem, 2 = also inside every problem of a batch
+    const bool seg = (seg_env == 1 && S == 1 && gx >= 64) || (seg_env == 2 && gx >= 2);
     const dim3 grid(gx, (unsigned)S), block(BLOCK);
     switch (loss_grad_variant()) {
-        case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
-        case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
-        case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
-        default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws); break;
+        case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+        case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+        case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+        default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
     }
     SYMODE_LAUNCH_CHECK();
     finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv_count, 2.0f * inv_count, loss,
