@@ -80,6 +80,36 @@ class _FusedMSE(torch.autograd.Function):
         return g * grad, None, None, None, None, None
 
 
+class _LstsqResidual(torch.autograd.Function):
+    """The value ``lm.residuals.mean() / N`` of the ridge least-squares solve as a differentiable function of
+    the data (x, y) -- what ``train_lassi`` back-propagates into the encoder (train.py:166-174).
+
+    By the envelope theorem the optimal coefficients need no derivative: with r = Theta(x) Xi*^T - y,
+    d res / dy = -2 c r  and  d res / dx = 2 c J_Theta(x)^T (Xi* r)  (c = the reference's averaging factor);
+    both come from the HIP forward and vjp kernels.  Forward returns the residual computed from the Gram.
+    """
+
+    @staticmethod
+    def forward(ctx, x, y, value, xi_sol, scale, reg):
+        ctx.reg, ctx.scale = reg, scale
+        ctx.save_for_backward(x, y, xi_sol)
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, xi = ctx.saved_tensors
+        reg = ctx.reg
+        d = reg.latent_dim
+        x2, y2 = x.detach().reshape(-1, d).contiguous(), y.detach().reshape(-1, d).contiguous()
+        r = reg.engine.forward(x2, xi, None, reg.poly_order, reg.flags) - y2
+        gy = (-2.0 * ctx.scale) * g * r
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx, _ = reg.engine.vjp(x2, ((2.0 * ctx.scale) * g * r).contiguous(), xi, None, reg.poly_order, reg.flags)
+            gx = gx.reshape(x.shape)
+        return gx, (gy.reshape(y.shape) if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
 class SINDyRegression(nn.Module):
     """
     Arguments (reference sindy.py:33-42):
@@ -309,9 +339,17 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
                 regressor.beta.data = torch.from_numpy(full[:-d].copy()).float().to(dev)
                 regressor.const.data = torch.from_numpy(full[-d:].copy()).float().view(-1, 1).to(dev)
             residual = yy - 2 * b @ cq + b @ Gq @ b
+    # coefficients of THIS solve (support = the mask it was solved on), before the new threshold is applied
+    xi_sol = ((regressor.get_Xi() if regressor.constraint else regressor.Xi).detach() * prev_mask).contiguous()
     regressor.set_threshold(st_threshold)                                   # sindy.py:312
     converged = torch.allclose(prev_mask, regressor.mask)                   # sindy.py:313
-    return torch.tensor(residual / N, dtype=torch.float32, device=dev), converged
+    value = torch.tensor(residual / N, dtype=torch.float32, device=dev)
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad) and x.is_cuda:
+        # lm.residuals is per right-hand side: d columns for the full-mask solve, one for the flattened system
+        per_col = mask.all() and not regressor.constraint
+        scale = 1.0 / (N * (d if per_col else 1))
+        value = _LstsqResidual.apply(x, y, value, xi_sol, scale, regressor)
+    return value, converged
 
 
 def solve_SINDy(regressor, x, y, w_sindy_reg, st_threshold, max_iter=5, **kwargs):

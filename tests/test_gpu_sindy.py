@@ -144,3 +144,42 @@ def test_gather_gram_and_seed_sweep_on_gpu(S, golden):
         assert len(hist) == passes[s]
         want = reg.Xi.detach().numpy()
         assert np.allclose(Xi[s].numpy(), want, rtol=1e-5, atol=2e-5 * np.abs(want).max())
+
+
+def test_lstsq_residual_is_differentiable_wrt_data(S):
+    """train_lassi's SINDy branch back-propagates the least-squares residual into the encoder (train.py:166-174):
+    d residual / d(z, dz) from the HIP kernels vs autograd through an fp64 ridge solve on the CPU."""
+    torch.manual_seed(0)
+    n, d, order, gamma = 64, 2, 2, 0.1                       # the rd latent batch: 64 points x 2 dims
+    z0, dz0 = torch.randn(n, d) * 0.7, torch.randn(n, d)
+
+    def reference(z, dz, mask):
+        th = O.theta(z, order)
+        p = th.shape[1]
+        total = 0.0
+        cols = 0
+        for j in range(d):
+            idx = mask[j].bool()
+            A = torch.cat([th[:, idx], gamma * torch.eye(p, dtype=z.dtype)[:, idx]], 0)
+            B = torch.cat([dz[:, j], torch.zeros(p, dtype=z.dtype)])
+            w = torch.linalg.solve(A.T @ A, A.T @ B)
+            total = total + ((A @ w - B) ** 2).sum()
+            cols += 1
+        return total
+
+    for partial in (False, True):
+        r = S.SINDyRegression(d, order, False, False, threshold=1e-9, device="cuda:0", lstsq_driver="gels")
+        mask = torch.ones(d, 6)
+        if partial:
+            mask[0, 3] = 0.0
+            mask[1, 5] = 0.0
+        r.mask = mask.cuda()
+        z, dz = z0.cuda().requires_grad_(True), dz0.cuda().requires_grad_(True)
+        res, _ = S.solve_SINDy_one_step(r, z, dz, gamma, 1e-9)
+        res.backward()
+        zr, dzr = z0.double().requires_grad_(True), dz0.double().requires_grad_(True)
+        want = reference(zr, dzr, mask) / (n * (1 if partial else d))
+        want.backward()
+        assert np.isclose(res.item(), want.item(), rtol=1e-4)
+        assert torch.allclose(dz.grad.cpu().double(), dzr.grad, rtol=1e-3, atol=1e-5 * dzr.grad.abs().max().item())
+        assert torch.allclose(z.grad.cpu().double(), zr.grad, rtol=1e-3, atol=1e-4 * zr.grad.abs().max().item())
