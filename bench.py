@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernel (default 1: one collective)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
+    ap.add_argument("--shard", choices=["points", "seeds"], default="points",
+                    help="N > 1: 'points' = every rank holds a shard of each problem's trajectories and the packed "
+                         "[loss|grad] partials are all-reduced (RCCL, default); 'seeds' = every rank owns whole problems, "
+                         "no data-path collective")
     ap.add_argument("--force_dist", action="store_true",
                     help="initialise the RCCL process group and run the collective path even with one rank (self-test)")
     ap.add_argument("--profile", action="store_true",
@@ -124,7 +128,7 @@ def main():
     Q = Q.to(dev)
     n_chunks = a.chunks or 1
     clos = BatchedClosure(x, dx, order, Q=Q, use_kron_product=use_kron, allow_constant=True,
-                          group=dist.group.WORLD if use_dist else None, n_chunks=n_chunks, engine=eng)
+                          group=dist.group.WORLD if (use_dist and a.shard == "points") else None, n_chunks=n_chunks, engine=eng)
     g = torch.Generator(device=dev)
     g.manual_seed(7 + rank)
     beta = torch.randn(S, Q.shape[1], generator=g, device=dev) * 0.3
@@ -221,9 +225,9 @@ def main():
         "config": {"workload": f"damped_oscillator n_ics={a.n_ics} steps={a.n_steps} dim=2 poly-order={order} "
                                f"EquivSINDy-c (so2), {S} (trajectory,seed) problems per GPU resident in HBM; "
                                f"step = closure (Xi from beta, fused Theta+residual+loss+grad kernel, grad->beta"
-                               f"{', RCCL all-reduce of [loss|grad]' if use_dist else ''})",
+                               f"{', RCCL all-reduce of [loss|grad]' if (use_dist and a.shard == 'points') else ''})",
                    "points_per_step_per_gpu": S * n_pts, "library_terms": clos.p,
-                   "parallelism": f"point-shard x{world}" if world > 1 else "single"},
+                   "parallelism": f"{a.shard[:-1]}-shard x{world}" if world > 1 else "single"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "loss_grad_kernel<Library<2,5,0>> (+ finalize)", "kernel_ms": kern_ms, "kernel_ms_min": kern_all[0], "kernel_ms_median": kern_all[len(kern_all) // 2],
