@@ -69,7 +69,7 @@ class _HostShadow:
     the reference's semantics.
     """
 
-    def __init__(self, regressor, x, dx, reversed_sym=None, numpy_vars=True):
+    def __init__(self, regressor, x, dx, reversed_sym=None, numpy_vars=True, use_graph=True):
         self.reg, self.x, self.dx = regressor, x, dx
         self.params = [p.detach().cpu().clone().requires_grad_(True) for p in regressor.parameters()]
         # numpy mode: ONE flat float32 vector aliases every host parameter (torch views of the same memory)
@@ -94,6 +94,41 @@ class _HostShadow:
         n_terms = 2 if reversed_sym is not None else 1
         self.d_out = torch.empty(n_terms * self.n_out, device=dev)
         self.h_out = torch.empty(n_terms * self.n_out).pin_memory()
+        self._graph = None
+        if use_graph:
+            self._capture()
+
+    def _launch(self):
+        """Upload coefficients, the fused kernels, download [loss | grad]: everything between the two host buffers."""
+        reg, (d, p), n = self.reg, self.mask.shape, self.n_out
+        self.d_xi.copy_(self.h_xi, non_blocking=True)
+        reg.engine.loss_grad(self.x, self.dx, self.d_xi, reg.mask, reg.poly_order, reg.flags,
+                             out=(self.d_out[:1], self.d_out[1:n].view(d, p)))
+        if self.reversed_sym is not None:
+            gx, jgx = self.reversed_sym
+            ls, gs = reg.engine.symreg_reversed(self.x, gx, jgx, self.d_xi, reg.mask, reg.poly_order, reg.flags)
+            self.d_out[n:n + 1].copy_(ls.reshape(1))
+            self.d_out[n + 1:].copy_(gs.reshape(-1))
+        self.h_out.copy_(self.d_out, non_blocking=True)
+
+    def _capture(self):
+        """The closure's device work is launch-bound (two ~6 us kernels between two tiny copies): capture it once
+        in a HIP graph and replay it per closure.  Any failure leaves the eager path in place."""
+        try:
+            self.h_xi.copy_(self.get_Xi().detach())
+            side = torch.cuda.Stream(device=self.x.device)
+            side.wait_stream(torch.cuda.current_stream(self.x.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._launch()                      # warm-up: workspace of the capture stream, lazy inits
+            torch.cuda.current_stream(self.x.device).wait_stream(side)
+            torch.cuda.synchronize(self.x.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch()
+            self._graph = g
+        except Exception:                               # pragma: no cover - depends on the runtime
+            self._graph = None
 
     def parameters(self):
         return self.params
@@ -120,7 +155,7 @@ class _HostShadow:
         with torch.no_grad():
             for dst, src in zip(self.reg.parameters(), self.params):
                 dst.data.copy_(src.detach())
-            self.reg.mask.data = self.mask.to(self.reg.mask.device)
+            self.reg.mask.copy_(self.mask)              # in place: the captured graph holds this pointer
 
     def grad_to_flat(self, g_xi):
         """Chain rule of get_Xi: dL/d(flat parameters) from dL/dXi (d, p), as numpy float32."""
@@ -137,16 +172,11 @@ class _HostShadow:
         reg, d, p = self.reg, *self.mask.shape
         Xi = self.get_Xi()
         self.h_xi.copy_(Xi.detach())
-        self.d_xi.copy_(self.h_xi, non_blocking=True)
         n = self.n_out
-        reg.engine.loss_grad(self.x, self.dx, self.d_xi, reg.mask, reg.poly_order, reg.flags,
-                             out=(self.d_out[:1], self.d_out[1:n].view(d, p)))
-        if self.reversed_sym is not None:
-            gx, jgx = self.reversed_sym
-            ls, gs = reg.engine.symreg_reversed(self.x, gx, jgx, self.d_xi, reg.mask, reg.poly_order, reg.flags)
-            self.d_out[n:n + 1].copy_(ls.reshape(1))
-            self.d_out[n + 1:].copy_(gs.reshape(-1))
-        self.h_out.copy_(self.d_out, non_blocking=True)
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._launch()
         torch.cuda.current_stream(self.x.device).synchronize()
         vals = [self.h_out[k * n].clone() for k in range(len(self.h_out) // n)]
         grads = [self.h_out[k * n + 1:(k + 1) * n].view(d, p).clone() for k in range(len(self.h_out) // n)]
@@ -366,7 +396,8 @@ def train_SIGED_lbfgs(
             from .model_utils import precompute_symmreg_r
             gx, jgx = precompute_symmreg_r(x, autoencoder, generator, scale=0.01)
             rev = (torch.stack(gx).contiguous(), torch.stack(jgx).contiguous())
-        shadow = _HostShadow(regressor, x, dx, reversed_sym=rev, numpy_vars=kwargs.get('numpy_lbfgs', False))
+        shadow = _HostShadow(regressor, x, dx, reversed_sym=rev, numpy_vars=kwargs.get('numpy_lbfgs', False),
+                             use_graph=kwargs.get('hip_graph', True))
 
         def closure_np(flat):                                                          # numpy variables: (loss, flat gradient)
             with torch.no_grad():
