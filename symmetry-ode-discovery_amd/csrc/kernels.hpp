@@ -300,19 +300,24 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 // K1: fused Theta + residual + MSE + gradient                  (closure body + backward)
 // ---------------------------------------------------------------------------------------
 // VARIANT selects the streaming schedule (kept as a template knob for A/B runs on the GPU,
-// SYMODE_LOSS_GRAD_VARIANT): 0 plain grid-stride loop; 2 two chunks per step; 4 = 2 with
-// non-temporal loads (default).  Measured on MI355X, S=1024 x 125000 points, d=2 (round 1):
-//   order 5: 0 -> 4.8 TB/s, 4 -> 5.3 TB/s;  order 3: 0 -> 5.6 TB/s, 4 -> 6.3 TB/s (alg. bytes).
-// A software-prefetch form (next chunk loaded before computing the current one) and forms with
-// sched_barrier between points were slower or equal; forcing 5-6 waves/SIMD (amdgpu_waves_per_eu) spills at
-// order 5 (8-11x slower) and 4 waves is within 1.3 % of the free allocation; -fno-slp-vectorize (Makefile) is worth
-// 6 % at order 5: packed fp32 FMAs force the uniform coefficients out of SGPRs into VGPR pairs.
+// SYMODE_LOSS_GRAD_VARIANT; tools/ab_variants.py runs them in one gpurun call and checks bit-identity):
+//   0 plain grid-stride loop; 2 two chunks per step; 4 = 2 with non-temporal loads;
+//   5 = 4 with a register double buffer (next step's loads issued before this step's VALU work) -- default;
+//   6 packed fp32 (below); 8 LDS-DMA ring.
+// Measured on MI355X, S = 2048 x 125000 points, d = 2 (round 1, algorithmic bytes / launch incl. finalize):
+//   order 5: 0 -> 4.8 TB/s, 4 -> 5.4 TB/s, 5 -> 5.55 TB/s;  order 3: 0 -> 5.6, 4 -> 6.35, 5 -> 6.45 TB/s.
+// Why order 5 stops there: 108 VALU ops per point = 422 K wave-instructions per SIMD per launch, and a SIMD with 3
+// resident waves retires one every 1.23 ns (tools/micro/valu_rate.hip), i.e. 0.52 ms of VALU beside 0.52-0.64 ms of
+// HBM stream in a 0.73 ms launch: both pipes are > 70 % busy.  Forms with sched_barrier between points were slower or
+// equal; forcing 5-6 waves/SIMD (amdgpu_waves_per_eu) spills at order 5 (8-11x slower) and 4 waves is within 1.3 % of
+// the free allocation; -fno-slp-vectorize (Makefile) is worth 6 % at order 5: SLP-packed FMAs force the uniform
+// coefficients out of SGPRs into VGPR pairs.
 template <class Lib, int VARIANT>
 __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, const float* __restrict__ dx, long N, bool vec,
                                                const float* __restrict__ xi, const float* __restrict__ mask,
                                                double* __restrict__ ws, const bool SEGMENTED) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
-    constexpr bool NT = (VARIANT == 4);
+    constexpr bool NT = (VARIANT == 4 || VARIANT == 5);
     const long s = blockIdx.y;
     const float* xs = x + s * N * D;
     const float* ys = dx + s * N * D;
@@ -364,7 +369,36 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
             c = lo + threadIdx.x;
             nthreads = BLOCK;
         }
-        if constexpr (VARIANT == 2 || VARIANT == 4) {
+        if constexpr (VARIANT == 5) {
+            // register double buffer: the next step's four 16-byte loads are issued before the current step's
+            // ~430 VALU ops, so a wave always has 4 KB in flight (addresses clamped: the tail over-reads in bounds)
+            if (nchunks_all > 0) {
+                const long lastc = nchunks_all - 1;
+                auto ld = [&](long cc, float4 (&vx)[NV], float4 (&vy)[NV]) {
+                    const long q = cc < lastc ? cc : lastc;
+                    load_chunk_raw<D, true>(xs, q, vx);
+                    load_chunk_raw<D, true>(ys, q, vy);
+                };
+                float4 ax[NV], ay[NV], bx[NV], by[NV];
+                ld(c, ax, ay);
+                ld(c + nthreads, bx, by);
+                for (; c + nthreads < nchunks; c += 2 * nthreads) {
+                    float4 nax[NV], nay[NV], nbx[NV], nby[NV];
+                    ld(c + 2 * nthreads, nax, nay);
+                    ld(c + 3 * nthreads, nbx, nby);
+                    chunk(ax, ay);
+                    chunk(bx, by);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        ax[i] = nax[i];
+                        ay[i] = nay[i];
+                        bx[i] = nbx[i];
+                        by[i] = nby[i];
+                    }
+                }
+                if (c < nchunks) chunk(ax, ay);
+            }
+        } else if constexpr (VARIANT == 2 || VARIANT == 4) {
             for (; c + nthreads < nchunks; c += 2 * nthreads) {
                 float4 ax[NV], ay[NV], bx[NV], by[NV];
                 load_chunk_raw<D, NT>(xs, c, ax);
@@ -443,12 +477,192 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
     emit_partials<NACC>(acc, ws);
 }
 
+// Packed-fp32 form of K1 (VARIANT 6, D <= 2; an A/B knob, not the default).
+// A lane carries two points (a, b) per step as the halves of 64-bit register pairs:
+//   Theta      th2[k] = (th_a[k], th_b[k])                         one v_pk_mul_f32 per column for both points
+//   residual   r_a (rows 2jp, 2jp+1) = sum_k w2[jp][k] * th_a[k]   v_pk_fma_f32, th broadcast by op_sel
+//   gradient   acc2[jp][k] += r_a * th_a[k]; += r_b * th_b[k]      v_pk_fma_f32 onto a (row pair, column) accumulator
+// which halves the VALU instruction count (228 instead of 432 per 4 points at order 5) without more accumulator
+// registers.  Every fp32 value is rounded exactly as in the scalar form and added in the same order (a then b), so
+// results are bit-identical for even D (checked on the GPU, tools/ab_variants.py); for odd D the last row keeps
+// separate a/b accumulators that are added once at the end.
+// Measured on MI355X (S = 2048 x 125000 points, d = 2): orders 2-5 within 1 % of the scalar form (order 5: 0.742 vs
+// 0.742 ms).  gfx950's SIMD retires a wave64 v_fma_f32 in 2 cycles and a v_pk_fma_f32 in 4, i.e. the same
+// 64 FLOP/clk/SIMD: packing saves issue slots, not VALU time, and issue slots are not what limits this kernel.
+template <class Lib>
+__device__ __forceinline__ void loss_grad_body_packed(const float* __restrict__ x, const float* __restrict__ dx, long N,
+                                                      bool vec, const float* __restrict__ xi,
+                                                      const float* __restrict__ mask, double* __restrict__ ws,
+                                                      const bool SEGMENTED) {
+    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
+    constexpr int JP = D / 2;
+    constexpr bool ODD = (D % 2) != 0;
+    constexpr int JL = D - 1;                 // the unpaired row when D is odd
+    const long s = blockIdx.y;
+    const float* xs = x + s * N * D;
+    const float* ys = dx + s * N * D;
+    float w[D * P];
+    load_xi<Lib>(xi, mask, s, w);
+    f2 acc2[JP > 0 ? JP : 1][P];              // rows (2jp, 2jp+1) x column k
+    f2 accl[P];                               // odd D: row JL, (points a, points b) kept apart
+    float acc0 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+#pragma unroll
+        for (int jp = 0; jp < JP; ++jp) acc2[jp][k] = splat(0.0f);
+        accl[k] = splat(0.0f);
+    }
+
+    auto pair = [&](const float (&xa)[D], const float (&ya)[D], const float (&xb)[D], const float (&yb)[D]) {
+        f2 x2[D], th2[P];
+#pragma unroll
+        for (int v = 0; v < D; ++v) x2[v] = f2{xa[v], xb[v]};
+        Lib::eval2(x2, th2);
+        f2 ra[JP > 0 ? JP : 1], rb[JP > 0 ? JP : 1], rl = splat(0.0f);
+#pragma unroll
+        for (int jp = 0; jp < JP; ++jp) {
+            f2 sa = splat(0.0f), sb = splat(0.0f);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const f2 w2 = f2{w[(2 * jp) * P + k], w[(2 * jp + 1) * P + k]};
+                sa = fma2(w2, splat_lo(th2[k]), sa);
+                sb = fma2(w2, splat_hi(th2[k]), sb);
+            }
+            ra[jp] = sa - f2{ya[2 * jp], ya[2 * jp + 1]};
+            rb[jp] = sb - f2{yb[2 * jp], yb[2 * jp + 1]};
+        }
+        if constexpr (ODD) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) rl = fma2(splat(w[JL * P + k]), th2[k], rl);
+            rl -= f2{ya[JL], yb[JL]};
+        }
+        // sum of squares in the scalar form's order: point a rows 0..D-1, then point b
+#pragma unroll
+        for (int jp = 0; jp < JP; ++jp) {
+            acc0 = fmaf(ra[jp].x, ra[jp].x, acc0);
+            acc0 = fmaf(ra[jp].y, ra[jp].y, acc0);
+        }
+        if constexpr (ODD) acc0 = fmaf(rl.x, rl.x, acc0);
+#pragma unroll
+        for (int jp = 0; jp < JP; ++jp) {
+            acc0 = fmaf(rb[jp].x, rb[jp].x, acc0);
+            acc0 = fmaf(rb[jp].y, rb[jp].y, acc0);
+        }
+        if constexpr (ODD) acc0 = fmaf(rl.y, rl.y, acc0);
+#pragma unroll
+        for (int jp = 0; jp < JP; ++jp)
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                acc2[jp][k] = fma2(ra[jp], splat_lo(th2[k]), acc2[jp][k]);
+                acc2[jp][k] = fma2(rb[jp], splat_hi(th2[k]), acc2[jp][k]);
+            }
+        if constexpr (ODD) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) accl[k] = fma2(rl, th2[k], accl[k]);
+        }
+    };
+    auto one = [&](const float (&xp)[D], const float (&yp)[D]) {      // ragged tails: scalar ops on the low halves
+        float th[P], r[D];
+        Lib::eval(xp, th);
+        apply_xi<Lib>(w, th, r);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            r[j] -= yp[j];
+            acc0 = fmaf(r[j], r[j], acc0);
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+#pragma unroll
+            for (int jp = 0; jp < JP; ++jp) acc2[jp][k] = fma2(f2{r[2 * jp], r[2 * jp + 1]}, splat(th[k]), acc2[jp][k]);
+            if constexpr (ODD) accl[k].x = fmaf(r[JL], th[k], accl[k].x);
+        }
+    };
+    auto chunk = [&](const float4 (&vx)[NV], const float4 (&vy)[NV]) {
+        float xp[PPT][D], yp[PPT][D];
+        unpack_chunk<D>(vx, xp);
+        unpack_chunk<D>(vy, yp);
+        if constexpr (PPT >= 2) {
+#pragma unroll
+            for (int i = 0; i < PPT; i += 2) pair(xp[i], yp[i], xp[i + 1], yp[i + 1]);
+        } else {
+            one(xp[0], yp[0]);
+        }
+    };
+    auto chunk2 = [&](const float4 (&ax)[NV], const float4 (&ay)[NV], const float4 (&bx)[NV], const float4 (&by)[NV]) {
+        if constexpr (PPT >= 2) {
+            chunk(ax, ay);
+            chunk(bx, by);
+        } else {                                                      // D = 4: the pair spans the step's two chunks
+            float xa[1][D], ya[1][D], xb[1][D], yb[1][D];
+            unpack_chunk<D>(ax, xa);
+            unpack_chunk<D>(ay, ya);
+            unpack_chunk<D>(bx, xb);
+            unpack_chunk<D>(by, yb);
+            pair(xa[0], ya[0], xb[0], yb[0]);
+        }
+    };
+    auto point = [&](long n) {
+        float xp[D], yp[D];
+        load_point<D>(xs, n, xp);
+        load_point<D>(ys, n, yp);
+        one(xp, yp);
+    };
+
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
+    long nthreads = (long)gridDim.x * BLOCK;
+    if (vec) {
+        const long nchunks_all = N / PPT;
+        long nchunks = nchunks_all;
+        long c = tid;
+        if (SEGMENTED) {
+            const long per = (nchunks_all + gridDim.x - 1) / gridDim.x;
+            const long lo = (long)blockIdx.x * per;
+            nchunks = lo + per < nchunks_all ? lo + per : nchunks_all;
+            c = lo + threadIdx.x;
+            nthreads = BLOCK;
+        }
+        for (; c + nthreads < nchunks; c += 2 * nthreads) {
+            float4 ax[NV], ay[NV], bx[NV], by[NV];
+            load_chunk_raw<D, true>(xs, c, ax);
+            load_chunk_raw<D, true>(ys, c, ay);
+            load_chunk_raw<D, true>(xs, c + nthreads, bx);
+            load_chunk_raw<D, true>(ys, c + nthreads, by);
+            chunk2(ax, ay, bx, by);
+        }
+        if (c < nchunks) {
+            float4 ax[NV], ay[NV];
+            load_chunk_raw<D, true>(xs, c, ax);
+            load_chunk_raw<D, true>(ys, c, ay);
+            chunk(ax, ay);
+        }
+        const long n = nchunks_all * PPT + tid;
+        if (n < N) point(n);
+    } else {
+        for (long n = tid; n < N; n += nthreads) point(n);
+    }
+    float acc[NACC];
+    acc[0] = acc0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+#pragma unroll
+        for (int jp = 0; jp < JP; ++jp) {
+            acc[1 + (2 * jp) * P + k] = acc2[jp][k].x;
+            acc[1 + (2 * jp + 1) * P + k] = acc2[jp][k].y;
+        }
+        if constexpr (ODD) acc[1 + JL * P + k] = accl[k].x + accl[k].y;
+    }
+    emit_partials<NACC>(acc, ws);
+}
+
 template <class Lib, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                           long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, double* __restrict__ ws,
                                                           bool segmented) {
-    loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws, segmented);
+    if constexpr (VARIANT == 6)
+        loss_grad_body_packed<Lib>(x, dx, N, vec, xi, mask, ws, segmented);
+    else
+        loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws, segmented);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -892,7 +1106,7 @@ hipError_t launch_odeint(const float* x, long n, const float* xi, const float* m
 inline int loss_grad_variant() {
     static const int v = [] {
         const char* e = getenv("SYMODE_LOSS_GRAD_VARIANT");
-        return e ? atoi(e) : 4;
+        return e ? atoi(e) : 5;
     }();
     return v;
 }
@@ -906,7 +1120,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // 2048 blocks over 768 resident slots (order 5) left a 2/3-empty last round (-20 % at N = 2^27).
     static const int resident = [] {
         int nb = 0, cu = 256, dev = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, 4>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, 5>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
         return nb * cu;
     }();
@@ -918,6 +1132,14 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     switch (loss_grad_variant()) {
         case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
         case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+        case 5: loss_grad_kernel<Lib, 5><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+        case 6:
+            if constexpr (Lib::D <= 2) {        // D = 3, 4: the pair layout needs > 256 VGPRs (spills); scalar form there
+                loss_grad_kernel<Lib, 6><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
+            } else {
+                loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
+            }
+            break;
         case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
         default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
     }
