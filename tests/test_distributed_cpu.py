@@ -88,3 +88,51 @@ def test_sharded_constrained_closure_gradients(tmp_path):
         assert np.isclose(r0["loss"][s], loss.item(), rtol=1e-5)
         assert np.allclose(r0["gb"][s], reg.beta.grad.numpy(), rtol=1e-4, atol=1e-6)
         assert np.allclose(r0["gc"][s], reg.const.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def _sweep_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import symode_amd  # noqa: F401
+    from symode_amd.batched import BatchedClosure
+    from symode_amd.sweep import SeedSweepLBFGS, SeedSweepSTLSQ
+    from tests.oracle_engine import OracleEngine
+    x, dx = O.rk4_trajectories(O.rhs_dosc, O.ics_dosc(8, np.random.RandomState(3)), 0.02, 300)
+    x = torch.from_numpy(x.reshape(-1, 2)).float()
+    dx = torch.from_numpy(dx.reshape(-1, 2)).float()
+    n = x.shape[0]
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    # (1) STLSQ sweep: per-rank Gram of the rank's subsample, all-reduced, solved on every rank
+    sw = SeedSweepSTLSQ(x[lo:hi], dx[lo:hi], 3, n_seeds=4, subsample=0.5, seed0=0, group=dist.group.WORLD,
+                        engine=OracleEngine())
+    Xi, mask, passes = sw.solve(0.0, 5e-2)
+    # (2) L-BFGS sweep over point shards: every inner iteration all-reduces the packed [loss | grad]
+    S = 3
+    xs, dxs = x[lo:hi].expand(S, -1, -1).contiguous(), dx[lo:hi].expand(S, -1, -1).contiguous()
+    clos = BatchedClosure(xs, dxs, 3, group=dist.group.WORLD, engine=OracleEngine())
+    g = torch.Generator().manual_seed(7)
+    P0 = torch.randn(S, 20, generator=g) * 0.1
+    out = SeedSweepLBFGS(clos, 0.1, 5e-2, 50).fit(P0, 60)
+    np.savez(os.path.join(out_dir, f"sweep{rank}.npz"), Xi=Xi.numpy(), mask=mask.numpy(), n_points=sw.n_points,
+             lb_mask=out["mask"].numpy(), lb_Xi=out["Xi"].numpy(), lb_done=out["finished"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_point_sharded_seed_sweeps_agree_on_every_rank_and_recover_dosc(tmp_path):
+    port = _free_port()
+    mp.spawn(_sweep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(tmp_path / f"sweep{r}.npz") for r in range(2)]
+    for k in ("Xi", "mask", "lb_mask", "lb_Xi"):
+        assert np.array_equal(r0[k], r1[k]), k                        # replicated solve: identical on every rank
+    want = np.zeros((2, 10), dtype=bool)
+    want[:, :6] = O.SINDY_TRUTH["dosc"] != 0                           # dx0 = -0.1 x0 - x1 ; dx1 = x0 - 0.1 x1
+    assert int(r0["n_points"]) == 2 * (1200 // 2)                      # 2 ranks x 50 % of 1200 local points
+    for s in range(4):
+        assert np.array_equal(r0["mask"][s] > 0, want)
+        assert np.allclose(r0["Xi"][s][want], [-0.1, -1.0, 1.0, -0.1], atol=2e-3)
+    assert r0["lb_done"].all()
+    for s in range(3):
+        assert np.array_equal(r0["lb_mask"][s] > 0, want)
+        assert np.allclose(r0["lb_Xi"][s][want], [-0.1, -1.0, 1.0, -0.1], atol=5e-3)
