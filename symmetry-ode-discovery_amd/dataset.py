@@ -6,11 +6,17 @@ files are absent (the authors distribute them out of band) trajectories are synt
 RK4 restatement in data.py using the README recipe sizes, and written under ./data like the
 reference's fallback (dataset.py:178-186).  GP smoothing is not reproduced: synthesised noisy data
 keep the exact derivative of the clean orbit.
+
+Reaction-diffusion tasks (``rd``, ``mt_rd``; dataset.py:59-159) read ``./data/reaction_diffusion.mat`` (fields t, x, y,
+uf, duf -- the SINDy-autoencoder example file, distributed out of band) when it exists; otherwise a rigidly rotating
+spiral wave of the same layout is synthesised (``synthetic_spiral``), whose snapshots live on a two-dimensional
+manifold with harmonic latent dynamics.  Multi-timestep ODE tasks (``mt_lv``, ``mt_selkov``) window the ODE files.
 """
 from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
@@ -57,12 +63,118 @@ class ODEDataset(Dataset):
         return self.x[idx], self.dx[idx]
 
 
+class MTODEDataset(Dataset):
+    """Windows of ``n_timesteps`` states, ``interval`` samples apart, along every trajectory
+    (reference dataset.py:203-241): item -> (x, dx) of shape (n_timesteps, d)."""
+
+    def __init__(self, path=data_path, ode_name='lv', mode='train', n_timesteps=2, interval=10, noise=0.0, smoothing=None):
+        super().__init__()
+        if n_timesteps < 2:
+            raise ValueError('n_timesteps must be greater than 1 for multi-timestep dataset')
+        base = ODEDataset(path=path, ode_name=ode_name, mode=mode, noise=noise, smoothing=smoothing)
+        self.n_ics, self.n_steps, self.input_dim, self.n_timesteps = base.n_ics, base.n_steps, base.input_dim, n_timesteps
+        x = base.x.reshape(base.n_ics, base.n_steps, base.input_dim)
+        dx = base.dx.reshape(base.n_ics, base.n_steps, base.input_dim)
+        starts = torch.arange(base.n_steps - n_timesteps * interval)
+        t_idx = starts[:, None] + interval * torch.arange(n_timesteps)[None, :]          # (windows, n_timesteps)
+        self.x = x[:, t_idx].reshape(-1, n_timesteps, base.input_dim)
+        self.dx = dx[:, t_idx].reshape(-1, n_timesteps, base.input_dim)
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, idx):
+        return self.x[idx], self.dx[idx]
+
+
+# synthetic stand-in for reaction_diffusion.mat: grid points per side, snapshots, time step (ode_dt_dict['rd']),
+# angular velocity of the spiral, half-width of the square domain
+RD_SYNTH = {'n': 128, 'n_samples': 1000, 'dt': 0.05, 'omega': 1.0, 'half_width': 10.0}
+
+
+def synthetic_spiral(n, n_samples, dt, omega, half_width):
+    """Rigidly rotating one-armed spiral u(x, y, t) = tanh(r) cos(theta - r + omega t) and its time derivative,
+    in the .mat layout: dict(t (T,1), x (n,1), y (n,1), uf (n,n,T), duf (n,n,T)).  The initial frame is the
+    initial condition of the lambda-omega example the reference's file was made from."""
+    axis = np.linspace(-half_width, half_width, n)
+    X, Y = np.meshgrid(axis, axis)
+    r, theta = np.sqrt(X * X + Y * Y), np.arctan2(Y, X)
+    t = np.arange(n_samples) * dt
+    phase = (theta - r)[:, :, None] + omega * t[None, None, :]
+    amp = np.tanh(r)[:, :, None]
+    return {'t': t[:, None], 'x': axis[:, None], 'y': axis[:, None], 'uf': amp * np.cos(phase), 'duf': -omega * amp * np.sin(phase)}
+
+
+def _load_reaction_diffusion(path):
+    if os.path.exists(path):
+        import scipy.io as sio
+        data = sio.loadmat(path)
+    else:
+        print(f'{path} not found. Synthesising a rotating-spiral field {RD_SYNTH}...')
+        data = synthetic_spiral(**RD_SYNTH)
+    uf = data['uf'] + 1e-6 * np.random.randn(*data['uf'].shape)                        # dataset.py:66-67, 124-125
+    duf = data['duf'] + 1e-6 * np.random.randn(*data['duf'].shape)
+    T = data['t'].size
+    split = {'train': np.arange(int(.8 * T)), 'val': np.arange(int(.8 * T), int(.9 * T)), 'test': np.arange(int(.9 * T), T)}
+    return data, uf, duf, split
+
+
+class ReactionDiffusionDataset(Dataset):
+    """Single snapshots (N = n*n,) of the field and its time derivative (reference dataset.py:59-116)."""
+
+    def __init__(self, path=f'{data_path}/reaction_diffusion.mat', mode='train'):
+        data, uf, duf, split = _load_reaction_diffusion(path)
+        idx = split[mode]
+        self.x = torch.from_numpy(uf[:, :, idx].reshape(-1, len(idx)).T.copy()).float()
+        self.dx = torch.from_numpy(duf[:, :, idx].reshape(-1, len(idx)).T.copy()).float()
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, idx):
+        return self.x[idx], self.dx[idx], self.dx[idx]
+
+
+class MultiTimestepReactionDiffusionDataset(Dataset):
+    """Item i -> (x, dx) of shape (n_timesteps, N): the n_timesteps consecutive snapshots that end before
+    sample i + n_timesteps of the split (reference dataset.py:119-159).  The snapshots are stored once; windows
+    are views."""
+
+    def __init__(self, path=f'{data_path}/reaction_diffusion.mat', n_timesteps=2, mode='train'):
+        data, uf, duf, split = _load_reaction_diffusion(path)
+        idx = split[mode]
+        self.n_timesteps = n_timesteps
+        self.x = torch.from_numpy(np.transpose(uf[:, :, idx], (2, 0, 1)).reshape(len(idx), -1).copy()).float()
+        self.dx = torch.from_numpy(np.transpose(duf[:, :, idx], (2, 0, 1)).reshape(len(idx), -1).copy()).float()
+
+    def __len__(self):
+        return max(self.x.shape[0] - self.n_timesteps, 0)
+
+    def __getitem__(self, idx):
+        return self.x[idx:idx + self.n_timesteps], self.dx[idx:idx + self.n_timesteps]
+
+
 def get_dataset(args):
+    """reference dataset.py:16-57"""
     task = args['task']
     if task in ('lv', 'selkov', 'dosc', 'growth'):
         tr = ODEDataset(ode_name=task, mode='train', noise=args['noise'], smoothing=args['smoothing'])
         va = ODEDataset(ode_name=task, mode='val', noise=args['noise'], smoothing=args['smoothing'])
         args['input_dim'] = tr[0][0].shape[-1]
-        return tr, va, args
-    raise NotImplementedError(f"task {task!r}: only the ODE tasks (lv, selkov, dosc, growth) are on the MI355X path; "
-                              "reaction-diffusion / multi-timestep discovery stay with the reference on stock PyTorch")
+    elif task in ('mt_lv', 'mt_selkov'):
+        win = {} if task == 'mt_lv' else {'n_timesteps': 2, 'interval': 50}
+        tr = MTODEDataset(ode_name=task[3:], mode='train', noise=args['noise'], smoothing=args['smoothing'], **win)
+        va = MTODEDataset(ode_name=task[3:], mode='val', noise=args['noise'], smoothing=args['smoothing'], **win)
+        args['input_dim'] = tr[0][0].shape[-1]
+        args['mt_data'] = True
+    elif task == 'rd':
+        tr, va = ReactionDiffusionDataset(mode='train'), ReactionDiffusionDataset(mode='val')
+        args['input_dim'] = tr[0][0].shape[0]
+        args['flatten'] = False
+    elif task == 'mt_rd':
+        tr, va = MultiTimestepReactionDiffusionDataset(mode='train'), MultiTimestepReactionDiffusionDataset(mode='val')
+        args['input_dim'] = tr[0][0].shape[1]
+        args['mt_data'] = True
+    else:
+        raise NotImplementedError
+    return tr, va, args

@@ -4,8 +4,8 @@
 
 args -> seed -> dataset -> loaders -> autoencoder / generator -> optional LaLiGAN load ->
 regressor (with the equivariance constraint when --eq_constraint) -> train fn -> checkpoints ->
-eval_results/<save_dir>/seed{seed}.npz, as main.py:18-140 of the reference.  Symmetry
-*discovery* (--mt_data, train_lassi) is out of scope and exits with a message.
+eval_results/<save_dir>/seed{seed}.npz, as main.py:18-140 of the reference.  Multi-timestep tasks
+(mt_rd, mt_lv, mt_selkov) go to train_lassi (autoencoder + LieGAN on stock PyTorch, latent SINDy on HIP).
 """
 from __future__ import annotations
 
@@ -19,7 +19,7 @@ from . import train as T
 from .autoencoder import AutoEncoder
 from .dataset import get_dataset
 from .evaluation import eval_sindy_regressor, sindy_truth
-from .lie import LieGenerator
+from .lie import Discriminator, LieGenerator
 from .parser_utils import get_args
 from .sindy import SINDyRegression
 
@@ -43,6 +43,7 @@ def main(argv=None):
     val_loader = DataLoader(val_dataset, batch_size=args['batch_size'], shuffle=False)
 
     autoencoder = AutoEncoder(**args).to(args['device'])
+    discriminator = Discriminator(**args).to(args['device'])
     generator = LieGenerator(**args).to(args['device'])
 
     laligan_path = args['load_laligan']
@@ -56,7 +57,7 @@ def main(argv=None):
         masks = torch.load(f'saved_models/{laligan_path}/generator_mask.pt', weights_only=True)
         generator.masks = [m.to(args['device']) if m is not None else None for m in masks]
     if args['fix_laligan']:
-        for module in (autoencoder, generator):
+        for module in (autoencoder, generator, discriminator):
             for param in module.parameters():
                 param.requires_grad = False
 
@@ -77,12 +78,13 @@ def main(argv=None):
         train_fn = T.train_SIGED_lbfgs
     else:
         train_fn = T.train_SIGED
-    train_fn(autoencoder=autoencoder, discriminator=None, generator=generator, regressor=regressor,
+    train_fn(autoencoder=autoencoder, discriminator=discriminator, generator=generator, regressor=regressor,
              regressor_dst=regressor_dst, train_loader=train_loader, test_loader=val_loader, **args)
 
     out = f'saved_models/{args["save_dir"]}'
     os.makedirs(out, exist_ok=True)
     torch.save(autoencoder.state_dict(), f'{out}/autoencoder.pt')
+    torch.save(discriminator.state_dict(), f'{out}/discriminator.pt')
     torch.save(generator.state_dict(), f'{out}/generator.pt')
     torch.save(generator.masks, f'{out}/generator_mask.pt')
     torch.save(regressor.state_dict(), f'{out}/regressor.pt')
@@ -91,6 +93,9 @@ def main(argv=None):
     if regressor_dst is not None:
         torch.save(regressor_dst.state_dict(), f'{out}/regressor.pt')  # overwrites, as main.py:116-117 does
 
+    if args['mt_data']:                                                # discovery runs have no truth table (main.py:120)
+        T.wandb.finish()
+        return regressor
     print('\n=== Evaluation ===\n')
     true_eq = sindy_truth[args['task']]
     regressor_eval = regressor_dst if args['distill_latent'] else regressor

@@ -16,6 +16,8 @@ There is no CPU fallback: tensors must live on the GPU.
 """
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -233,13 +235,17 @@ class SINDyRegression(nn.Module):
 
     # ------------------------------------------------------------------ Gram access
     def aug_gram(self, x, y):
-        """fp64 [Theta | y]^T [Theta | y] on the host, cached while (x, y) are unchanged."""
-        key = (x.data_ptr(), x._version, tuple(x.shape), y.data_ptr(), y._version, self.poly_order, self.flags)
-        if self._gram_cache is None or self._gram_cache[0] != key:
-            G = self.engine.aug_gram(x.reshape(-1, self.latent_dim), y.reshape(-1, self.latent_dim), self.poly_order,
-                                     self.flags)
-            self._gram_cache = (key, G.cpu().numpy())
-        return self._gram_cache[1]
+        """fp64 [Theta | y]^T [Theta | y] on the host, cached while the SAME tensor objects (x, y) are unchanged
+        (identity through weak references + version counters: an address can be recycled by the allocator, e.g. the
+        encoder output of the next batch, a live object cannot)."""
+        c = self._gram_cache
+        hit = (c is not None and c[0]() is x and c[1]() is y and c[2] == (x._version, y._version, self.poly_order, self.flags))
+        if not hit:
+            G = self.engine.aug_gram(x.detach().reshape(-1, self.latent_dim), y.detach().reshape(-1, self.latent_dim),
+                                     self.poly_order, self.flags)
+            c = (weakref.ref(x), weakref.ref(y), (x._version, y._version, self.poly_order, self.flags), G.cpu().numpy())
+            self._gram_cache = c
+        return c[3]
 
 
 def _normal_system(regressor, G, gamma):
@@ -344,7 +350,7 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
     regressor.set_threshold(st_threshold)                                   # sindy.py:312
     converged = torch.allclose(prev_mask, regressor.mask)                   # sindy.py:313
     value = torch.tensor(residual / N, dtype=torch.float32, device=dev)
-    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad) and x.is_cuda:
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
         # lm.residuals is per right-hand side: d columns for the full-mask solve, one for the flattened system
         per_col = mask.all() and not regressor.constraint
         scale = 1.0 / (N * (d if per_col else 1))

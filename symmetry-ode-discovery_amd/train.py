@@ -9,8 +9,10 @@ closures runs on the HIP engine:
   * ``odeint`` / jvp-through-odeint of the symmetry terms -> fused integrator / analytic tangent flow;
   * ``solve_SINDy_one_step`` -> fp64 Gram (MFMA) + host solve.
 
-``train_lassi`` (joint autoencoder + LieGAN discovery) is out of scope (north_star: that path
-stays on stock PyTorch) and raises.
+``train_lassi`` (joint autoencoder + LieGAN symmetry discovery with a latent SINDy model, BASELINE
+config 5) keeps the autoencoder, generator and discriminator on stock PyTorch-ROCm, as north_star asks; its
+SINDy branch -- ``regressor(z)`` with backward into the encoder, or the latent least-squares solve whose
+residual is differentiable w.r.t. z -- runs on the HIP engine.
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ import torch
 
 from .model_utils import (_EulerFlow, make_fsymmreg_pttrain, make_rsymmreg_pttrain, make_symmreg_pttrain, odeint,
                           symmreg_linear)
-from .sindy import solve_SINDy_one_step
+from .sindy import solve_SINDy, solve_SINDy_one_step
 
 try:                                    # wandb is optional (absent offline; README: WANDB_MODE=disabled)
     import wandb
@@ -51,9 +53,225 @@ def _save(regressor, save_dir, name):
     torch.save(regressor.state_dict(), f'saved_models/{save_dir}/{name}')
 
 
-def train_lassi(*args, **kwargs):
-    raise NotImplementedError('train_lassi (autoencoder + LieGAN symmetry discovery) is outside the MI355X hot path; '
-                              'run it with the reference on stock PyTorch-ROCm and load its checkpoints (--load_laligan).')
+class _RunningMeans:
+    """Per-epoch means of the logged scalars."""
+
+    def __init__(self, keys):
+        self.values = {k: [] for k in keys}
+
+    def add(self, key, value):
+        self.values[key].append(value.item() if torch.is_tensor(value) else float(value))
+
+    def means(self):
+        return {k: (float(np.mean(v)) if len(v) else float('nan')) for k, v in self.values.items()}
+
+    def line(self, prefix, shown):
+        m = self.means()
+        return ', '.join([prefix] + [f'{k}: {m[k]:.4f}' for k in self.values if shown.get(k, False)])
+
+
+_LASSI_TRAIN_KEYS = ('loss_ae', 'loss_g', 'loss_reg_norm', 'loss_reg_ortho', 'loss_reg_closure', 'loss_d_real', 'loss_d_fake',
+                     'loss_ae_rel', 'loss_sindy_x', 'loss_sindy_z', 'loss_sindy_reg')
+_LASSI_TEST_KEYS = ('test_loss_ae', 'test_loss_g', 'test_loss_d_real', 'test_loss_d_fake', 'test_loss_sindy_x', 'test_loss_sindy_z')
+
+
+def _latent_generators(generator, n_comps):
+    """The generator's current basis cut to one component: the (d, d) blocks the regressor is constrained by
+    (train.py:162-164, main.py:69-73)."""
+    full = generator.get_full_basis_list()
+    d = full[0].shape[-1] // n_comps
+    return [L[:d, :d].detach().cpu() for L in full]
+
+
+def train_lassi(
+    autoencoder, discriminator, generator, train_loader, test_loader,
+    num_epochs, lr_ae, lr_d, lr_g, w_recon, w_gan, w_reg_norm, w_reg_sim, w_reg_ortho, w_reg_closure,
+    use_original_x, gan_st_freq, gan_st_thres, ae_arch,
+    include_sindy, regressor, lr_sindy, w_sindy_z, w_sindy_x, sindy_reg_type, w_sindy_reg, st_freq, threshold,
+    device, log_interval, save_interval, save_dir, **kwargs
+):
+    """Joint training of autoencoder, Lie generator, discriminator and a latent SINDy model on multi-timestep
+    batches x, dx (B, n_timesteps, input_dim) -- reference train.py:16-253, same arguments, same per-batch loss,
+    same epoch events (generator / regressor thresholding, checkpoints under saved_models/<save_dir>/*_{epoch}.pt).
+
+    SINDy branch: with ``w_sindy_x > 0`` the regressor is trained by Adam (lr x10 after each of the first three
+    epochs) on  w_z * MSE(regressor(z), dz) + w_x^2 * MSE(J_dec dz_pred, dx)  (the reference scales loss_sindy_x by
+    w_sindy_x twice, train.py:145, 148) + L1; otherwise its parameters are frozen and re-solved every batch by
+    sequential-threshold least squares on (z_0, dz_0), the solve's residual being the loss that reaches the encoder;
+    under the equivariance constraint Q is rebuilt when the learned generators have moved by more than 0.1 (summed
+    Frobenius distance) or on the last batch of an epoch.
+    """
+    train_ae = (ae_arch != 'none')
+    opt = {'d': torch.optim.Adam(discriminator.parameters(), lr=lr_d), 'g': torch.optim.Adam(generator.parameters(), lr=lr_g)}
+    if train_ae:
+        opt['ae'] = torch.optim.Adam(autoencoder.parameters(), lr=lr_ae)
+    scheduler = None
+    fit_by_adam = include_sindy and w_sindy_x > 0.0
+    if fit_by_adam:
+        opt['sindy'] = torch.optim.Adam(regressor.parameters(), lr=lr_sindy)
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(opt['sindy'], milestones=[1, 2, 3], gamma=10)
+    elif include_sindy:
+        for p in regressor.parameters():
+            p.requires_grad = False
+    else:
+        w_sindy_z = w_sindy_x = w_sindy_reg = 0.0
+    bce, mse = torch.nn.BCELoss(), torch.nn.MSELoss()
+
+    shown = dict(zip(_LASSI_TRAIN_KEYS, [w > 0 for w in (w_recon, w_gan, w_reg_norm, w_reg_ortho, w_reg_closure, w_gan, w_gan,
+                                                         w_recon, w_sindy_x, w_sindy_z, w_sindy_reg)]))
+    shown_test = dict(zip(_LASSI_TEST_KEYS, [w > 0 for w in (w_recon, w_gan, w_gan, w_gan, w_sindy_x, w_sindy_z)]))
+
+    def sindy_terms(log, x, dx, z, last_batch):
+        """loss contribution of the latent SINDy model for one batch"""
+        dz = autoencoder.compute_dz(x, dx)
+        if fit_by_adam:
+            dz_pred = regressor(z)
+            dx_pred = autoencoder.compute_dx(z, dz_pred)
+            on_z = mse(dz_pred, dz)
+            on_x = w_sindy_x * mse(dx_pred, dx)
+            log.add('loss_sindy_z', on_z)
+            log.add('loss_sindy_x', on_x)
+            total = w_sindy_z * on_z + w_sindy_x * on_x
+            if sindy_reg_type != 'l1':
+                raise ValueError(f'Unknown regularization type: {sindy_reg_type}')
+            l1 = sum(torch.norm(p, 1) for p in regressor.parameters())
+            log.add('loss_sindy_reg', l1)
+            return total + w_sindy_reg * l1
+        if regressor.constraint:
+            with torch.no_grad():
+                current = _latent_generators(generator, kwargs['n_comps'])
+                moved = sum(torch.norm(a - b) for a, b in zip(current, regressor.L_list))
+                if moved > 0.1 or last_batch:
+                    regressor.update_Q(current)
+        residual = solve_SINDy(regressor, z[:, 0], dz[:, 0], w_sindy_reg, threshold)
+        log.add('loss_sindy_z', residual)
+        log.add('loss_sindy_x', 0.0)
+        log.add('loss_sindy_reg', 0.0)
+        return w_sindy_z * residual
+
+    n_batches = len(train_loader)
+    for epoch in range(num_epochs):
+        log = _RunningMeans(_LASSI_TRAIN_KEYS)
+        for m in (autoencoder, discriminator, generator):
+            m.train()
+        if include_sindy:
+            regressor.train()
+        for i, (x, dx) in enumerate(train_loader):
+            x = x.to(device)
+            if include_sindy:
+                dx = dx.to(device)
+            real = torch.ones((x.shape[0], 1), device=device)
+            fake = torch.zeros((x.shape[0], 1), device=device)
+
+            # autoencoder
+            z, xhat = autoencoder(x)
+            loss_ae = mse(xhat, x)
+            log.add('loss_ae', loss_ae)
+            log.add('loss_ae_rel', loss_ae / mse(x, torch.zeros_like(x)))
+            loss = w_recon * loss_ae
+
+            # generator: a random group element moves the latent batch; the critic should not notice
+            zt = generator(z)
+            xt = autoencoder.decode(zt) if use_original_x else None
+            loss_g = bce(discriminator(zt, None, xt), real)
+            log.add('loss_g', loss_g)
+            loss = loss + w_gan * loss_g
+            if not np.isclose(w_reg_norm, 0.0):
+                reg = generator.reg_norm()
+                loss = loss + w_reg_norm * reg
+            elif not np.isclose(w_reg_sim, 0.0):             # or: transformed and original latents should differ
+                reg = torch.abs(torch.nn.CosineSimilarity(dim=-1)(zt, z).mean())
+                loss = loss + w_reg_sim * reg
+            else:
+                reg = 0.0
+            log.add('loss_reg_norm', reg)
+            for key, weight, term in (('loss_reg_ortho', w_reg_ortho, generator.reg_ortho),
+                                      ('loss_reg_closure', w_reg_closure, generator.reg_closure)):
+                if not np.isclose(weight, 0.0):
+                    value = term()
+                    loss = loss + weight * value
+                    log.add(key, value)
+                else:
+                    log.add(key, 0.0)
+
+            # discriminator on detached latents
+            xd = xhat.detach() if use_original_x else None
+            xtd = xt.detach() if use_original_x else None
+            loss_d_real = bce(discriminator(z.detach(), xd), real)      # (sic) second positional slot, as train.py:132-133
+            loss_d_fake = bce(discriminator(zt.detach(), xtd), fake)
+            log.add('loss_d_real', loss_d_real)
+            log.add('loss_d_fake', loss_d_fake)
+            loss = loss + (loss_d_real + loss_d_fake) / 2
+
+            if include_sindy:
+                loss = loss + sindy_terms(log, x, dx, z, last_batch=(i == n_batches - 1))
+            else:
+                for key in ('loss_sindy_z', 'loss_sindy_x', 'loss_sindy_reg'):
+                    log.add(key, 0.0)
+
+            for o in opt.values():
+                o.zero_grad()
+            loss.backward()
+            for name in ('ae', 'd', 'g', 'sindy'):
+                if name in opt:
+                    opt[name].step()
+
+        if scheduler is not None:
+            scheduler.step()
+        if gan_st_freq > 0 and (epoch + 1) % gan_st_freq == 0:
+            generator.set_threshold(gan_st_thres)
+        if fit_by_adam and st_freq > 0 and (epoch + 1) % st_freq == 0:
+            regressor.set_threshold(threshold)
+
+        record = log.means()
+        if (epoch + 1) % log_interval == 0:
+            print(log.line(f'Epoch {epoch}', shown))
+            for m in (autoencoder, discriminator, generator):
+                m.eval()
+            tlog = _RunningMeans(_LASSI_TEST_KEYS)
+            for x, dx in test_loader:
+                x, dx = x.to(device), dx.to(device)
+                with torch.no_grad():
+                    real = torch.ones((x.shape[0], 1), device=device)
+                    fake = torch.zeros((x.shape[0], 1), device=device)
+                    z, xhat = autoencoder(x)
+                    zt = generator(z)
+                    xt = autoencoder.decode(zt)
+                    d_fake = discriminator(zt, None, xt if use_original_x else None)
+                    d_real = discriminator(z, None, x if use_original_x else None)
+                    tlog.add('test_loss_ae', mse(xhat, x))
+                    tlog.add('test_loss_g', bce(d_fake, real))
+                    tlog.add('test_loss_d_real', bce(d_real, real))
+                    tlog.add('test_loss_d_fake', bce(d_fake, fake))
+                if include_sindy:
+                    dz = autoencoder.compute_dz(x, dx)          # functional jvp: builds its own graph, returns detached
+                    with torch.no_grad():
+                        dz_pred = regressor(z)
+                    dx_pred = autoencoder.compute_dx(z, dz_pred)
+                    tlog.add('test_loss_sindy_z', mse(dz_pred, dz))
+                    tlog.add('test_loss_sindy_x', mse(dx_pred, dx))
+                else:
+                    tlog.add('test_loss_sindy_z', 0.0)
+                    tlog.add('test_loss_sindy_x', 0.0)
+            record.update(tlog.means())
+            print(tlog.line(f'Epoch {epoch}', shown_test))
+            if kwargs.get('print_li'):
+                print(generator.getLi())
+            if include_sindy:
+                regressor.print()
+        wandb.log(record)
+
+        if (epoch + 1) % save_interval == 0:
+            out = f'saved_models/{save_dir}'
+            os.makedirs(out, exist_ok=True)
+            torch.save(autoencoder.state_dict(), f'{out}/autoencoder_{epoch}.pt')
+            torch.save(discriminator.state_dict(), f'{out}/discriminator_{epoch}.pt')
+            torch.save(generator.state_dict(), f'{out}/generator_{epoch}.pt')
+            torch.save(generator.masks, f'{out}/generator_mask_{epoch}.pt')
+            if include_sindy:
+                torch.save(regressor.state_dict(), f'{out}/regressor_{epoch}.pt')
+                torch.save(regressor.L_list, f'{out}/regressor_lie_list_{epoch}.pt')
+    return record
 
 
 class _HostShadow:

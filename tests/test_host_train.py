@@ -113,7 +113,10 @@ def test_train_sindy_loop(golden, capsys):
     assert "Final convergence reached at iteration 1" in capsys.readouterr().out
 
 
-def test_train_lassi_is_out_of_scope():
-    from symode_amd.train import train_lassi
+def test_unknown_tasks_and_autoencoders_raise_like_the_reference():
+    from symode_amd.autoencoder import AutoEncoder
+    from symode_amd.dataset import get_dataset
+    with pytest.raises(NotImplementedError):                   # dataset.py:56
+        get_dataset({"task": "nope", "noise": 0.0, "smoothing": None})
     with pytest.raises(NotImplementedError):
-        train_lassi()
+        AutoEncoder(ae_arch="stick_cnn")

@@ -489,8 +489,62 @@ def f8_known_answers():
     save("f8_known_answers", **arrays)
 
 
+def _flat_state(module, prefix):
+    return {f"{prefix}/{k}": v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def f9_lassi():
+    """N2 / BASELINE config 5: two epochs of the reference's train_lassi (Adam branch of the latent SINDy model,
+    w_sindy_x > 0 -- its lstsq branch returns NaN on the CPU, see f3) on a tiny multi-timestep field; initial and
+    final state_dicts of every module, the data and the logged epoch means.  Two variants: 'plain' (no batch norm:
+    every quantity is well conditioned) and 'bn' (batch norm as in rd/sym_eq.cfg: the biases in front of a BatchNorm
+    have zero true gradient, Adam turns their rounding noise into +-lr steps, so they and the eval-mode statistics
+    that depend on them are reproducible only loosely)."""
+    rng = np.random.RandomState(909)
+    T, N, dt, om = 40, 30, 0.05, 1.3
+    A, B = rng.randn(N), rng.randn(N)
+    t = np.arange(T + 1) * dt
+    field = np.outer(np.cos(om * t), A) + np.outer(np.sin(om * t), B) + 0.1 * np.outer(np.cos(2 * om * t), A * B)
+    dfield = om * (-np.outer(np.sin(om * t), A) + np.outer(np.cos(om * t), B)) - 0.2 * om * np.outer(np.sin(2 * om * t), A * B)
+    x = torch.tensor(np.stack([field[:-1], field[1:]], 1), dtype=torch.float32)        # (T, 2, N)
+    dx = torch.tensor(np.stack([dfield[:-1], dfield[1:]], 1), dtype=torch.float32)
+    ds_train = torch.utils.data.TensorDataset(x[:32], dx[:32])
+    ds_val = torch.utils.data.TensorDataset(x[32:], dx[32:])
+    arrays = {"x": x, "dx": dx, "n_train": np.array(32)}
+    for tag, bn in (("plain", False), ("bn", True)):
+        args = dict(ae_arch="mlp", input_dim=N, hidden_dim=16, latent_dim=2, n_layers=2, n_comps=2, activation="ReLU",
+                    activation_args=[], batch_norm=bn, ortho_ae=False,
+                    repr="(2,1,2)", group_idx="0", uniform_max=1, coef_dist="normal", g_init="random", task="mt_rd", sigma_init=1,
+                    int_param=False, int_param_noise=0.1, int_param_max=2, gan_st_thres=0.05, keep_center=True, device="cpu",
+                    use_original_x=False, use_invariant_y=False)
+        torch.manual_seed(9)
+        ae = ref_ae.AutoEncoder(**args)
+        disc = ref_gan.Discriminator(**args)
+        gen = ref_gan.LieGenerator(**args)
+        reg = make_regressor(2, 2, threshold=0.1)
+        for name, m in (("ae", ae), ("disc", disc), ("gen", gen), ("reg", reg)):
+            arrays.update(_flat_state(m, f"{tag}/init_{name}"))
+        torch.manual_seed(10)
+        tl = torch.utils.data.DataLoader(ds_train, batch_size=8, shuffle=True)
+        vl = torch.utils.data.DataLoader(ds_val, batch_size=8, shuffle=False)
+        _wandb_log.clear()
+        quiet(ref_train.train_lassi, ae, disc, gen, tl, vl, num_epochs=2, lr_ae=1e-3, lr_d=2e-3, lr_g=1e-2, w_recon=1.0, w_gan=0.01,
+              w_reg_norm=0.0, w_reg_sim=0.1, w_reg_ortho=0.05, w_reg_closure=0.0, use_original_x=False, gan_st_freq=2,
+              gan_st_thres=0.05, ae_arch="mlp", include_sindy=True, regressor=reg, lr_sindy=1e-3, w_sindy_z=0.1, w_sindy_x=0.5,
+              sindy_reg_type="l1", w_sindy_reg=1e-3, st_freq=1, threshold=0.1, device="cpu", log_interval=1,
+              save_interval=1000, save_dir="golden-lassi", n_comps=2, print_li=False)
+        for name, m in (("ae", ae), ("disc", disc), ("gen", gen), ("reg", reg)):
+            arrays.update(_flat_state(m, f"{tag}/final_{name}"))
+        arrays[f"{tag}/final_reg_mask"] = reg.mask
+        arrays[f"{tag}/final_gen_mask"] = gen.masks[0]
+        keys = sorted(_wandb_log[0].keys())
+        arrays["log_keys"] = np.array(keys)
+        arrays[f"{tag}/log_values"] = np.array([[float(e[k]) for k in keys] for e in _wandb_log])
+    save("f9_lassi", **arrays)
+
+
 ALL = {"f1": f1_theta, "f2": f2_fwd_loss_grad, "f3": f3_stlsq, "f4": f4_lbfgs, "f5": f5_constraint,
-       "f6": f6_symreg, "f7": f7_wsindy, "f8": f8_known_answers}
+       "f6": f6_symreg, "f7": f7_wsindy, "f8": f8_known_answers, "f9": f9_lassi}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
