@@ -80,6 +80,8 @@ inline bool vec_ok(const void* p, long n, int d, long S) {
     return ((uintptr_t)p % 16 == 0) && (S == 1 || (n * d) % 4 == 0);
 }
 
+constexpr int SGPR_XI_MAX = 48;     // largest D*P kept in SGPRs (the wave has ~100 of them; d = 2 up to order 5 fits)
+
 // Masked coefficients of problem s into registers (uniform across the block -> scalar loads).
 template <class Lib>
 __device__ __forceinline__ void load_xi(const float* __restrict__ xi, const float* __restrict__ mask, long s,
@@ -92,6 +94,13 @@ __device__ __forceinline__ void load_xi(const float* __restrict__ xi, const floa
         const float* m = mask + s * DP;
 #pragma unroll
         for (int i = 0; i < DP; ++i) w[i] *= m[i];
+    }
+    // The masked product is a VALU result; for small libraries hand it back to the scalar file (the values are
+    // wave-uniform) so that the hot loops read Xi as SGPR operands and the D*P VGPRs go to occupancy instead.
+    if constexpr (DP <= SGPR_XI_MAX) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i)
+            w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[i])));
     }
 }
 
@@ -302,10 +311,13 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 // VARIANT selects the streaming schedule (kept as a template knob for A/B runs on the GPU,
 // SYMODE_LOSS_GRAD_VARIANT; tools/ab_variants.py runs them in one gpurun call and checks bit-identity):
 //   0 plain grid-stride loop; 2 two chunks per step; 4 = 2 with non-temporal loads;
-//   5 = 4 with a register double buffer (next step's loads issued before this step's VALU work) -- default;
+//   5 = 4 with a register double buffer (next step's loads issued before this step's VALU work);
+//   7 = register ring of 4 chunk slots, each refilled right after use (6-8 KB in flight per wave) -- default;
 //   6 packed fp32 (below); 8 LDS-DMA ring.
 // Measured on MI355X, S = 2048 x 125000 points, d = 2 (round 1, algorithmic bytes / launch incl. finalize):
-//   order 5: 0 -> 4.8 TB/s, 4 -> 5.4 TB/s, 5 -> 5.55 TB/s;  order 3: 0 -> 5.6, 4 -> 6.35, 5 -> 6.45 TB/s.
+//   order 5: 0 -> 4.8 TB/s, 4 -> 5.4, 5 -> 5.55, 7 -> 5.65 TB/s;  order 3: 0 -> 5.6, 4 -> 6.35, 5 and 7 -> 6.45 TB/s.
+// With Xi in SGPRs (load_xi) the order-5 kernel needs 126 VGPRs (4 waves/SIMD); keeping Xi in VGPRs (146, 3 waves)
+// measured the same, as did grid widths 4096-16384: nothing but the two pipes themselves is left to tune.
 // Why order 5 stops there: 108 VALU ops per point = 422 K wave-instructions per SIMD per launch, and a SIMD with 3
 // resident waves retires one every 1.23 ns (tools/micro/valu_rate.hip), i.e. 0.52 ms of VALU beside 0.52-0.64 ms of
 // HBM stream in a 0.73 ms launch: both pipes are > 70 % busy.  Forms with sched_barrier between points were slower or
@@ -317,7 +329,7 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
                                                const float* __restrict__ xi, const float* __restrict__ mask,
                                                double* __restrict__ ws, const bool SEGMENTED) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
-    constexpr bool NT = (VARIANT == 4 || VARIANT == 5);
+    constexpr bool NT = (VARIANT == 4 || VARIANT == 5 || VARIANT == 7);
     const long s = blockIdx.y;
     const float* xs = x + s * N * D;
     const float* ys = dx + s * N * D;
@@ -397,6 +409,32 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
                     }
                 }
                 if (c < nchunks) chunk(ax, ay);
+            }
+        } else if constexpr (VARIANT == 7) {
+            // register ring of R chunk slots, each refilled right after it is consumed: R-1 chunks (x and dx) always
+            // in flight per lane, no register copies (the slot loop is unrolled), same chunk order as the other forms
+            constexpr int R = 4;
+            if (nchunks_all > 0) {
+                const long lastc = nchunks_all - 1;
+                auto ld = [&](long cc, float4 (&vx)[NV], float4 (&vy)[NV]) {
+                    const long q = cc < lastc ? cc : lastc;
+                    load_chunk_raw<D, true>(xs, q, vx);
+                    load_chunk_raw<D, true>(ys, q, vy);
+                };
+                float4 rx[R][NV], ry[R][NV];
+#pragma unroll
+                for (int k = 0; k < R; ++k) ld(c + k * nthreads, rx[k], ry[k]);
+                for (; c + (R - 1) * nthreads < nchunks; c += R * nthreads) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        chunk(rx[k], ry[k]);
+                        ld(c + (R + k) * nthreads, rx[k], ry[k]);
+                        __builtin_amdgcn_sched_barrier(0);       // keep the refill here: the scheduler would sink all R to the loop end
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    if (c + k * nthreads < nchunks) chunk(rx[k], ry[k]);
             }
         } else if constexpr (VARIANT == 2 || VARIANT == 4) {
             for (; c + nthreads < nchunks; c += 2 * nthreads) {
@@ -1106,7 +1144,7 @@ hipError_t launch_odeint(const float* x, long n, const float* xi, const float* m
 inline int loss_grad_variant() {
     static const int v = [] {
         const char* e = getenv("SYMODE_LOSS_GRAD_VARIANT");
-        return e ? atoi(e) : 5;
+        return e ? atoi(e) : 7;
     }();
     return v;
 }
@@ -1120,7 +1158,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // 2048 blocks over 768 resident slots (order 5) left a 2/3-empty last round (-20 % at N = 2^27).
     static const int resident = [] {
         int nb = 0, cu = 256, dev = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, 5>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, 7>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
         return nb * cu;
     }();
@@ -1140,6 +1178,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
                 loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
             }
             break;
+        case 7: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
         case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
         default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
     }
