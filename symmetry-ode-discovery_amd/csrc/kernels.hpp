@@ -1144,7 +1144,7 @@ hipError_t launch_odeint(const float* x, long n, const float* xi, const float* m
 inline int loss_grad_variant() {
     static const int v = [] {
         const char* e = getenv("SYMODE_LOSS_GRAD_VARIANT");
-        return e ? atoi(e) : 7;
+        return e ? atoi(e) : -1;          // -1: the library's own default
     }();
     return v;
 }
@@ -1158,7 +1158,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // 2048 blocks over 768 resident slots (order 5) left a 2/3-empty last round (-20 % at N = 2^27).
     static const int resident = [] {
         int nb = 0, cu = 256, dev = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, 7>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, ((Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX)) ? 7 : 4>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
         return nb * cu;
     }();
@@ -1167,20 +1167,28 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // contiguous slab per workgroup: 1 = for one big problem, 2 = also inside every problem of a batch
     const bool seg = (seg_env == 1 && S == 1 && gx >= 64) || (seg_env == 2 && gx >= 2);
     const dim3 grid(gx, (unsigned)S), block(BLOCK);
-    switch (loss_grad_variant()) {
-        case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-        case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-        case 5: loss_grad_kernel<Lib, 5><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-        case 6:
-            if constexpr (Lib::D <= 2) {        // D = 3, 4: the pair layout needs > 256 VGPRs (spills); scalar form there
-                loss_grad_kernel<Lib, 6><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
-            } else {
-                loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
-            }
-            break;
-        case 7: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-        case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-        default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+    // The register-ring / prefetch / packed forms pay only where the library leaves registers for them: d = 2 with Xi
+    // in SGPRs (every task the reference ships).  Larger libraries (d = 3, 4 at orders 3-4: 390-430 VGPRs already)
+    // would spill, so they keep the two-chunk form and the experimental variants are not even instantiated for them.
+    constexpr bool TUNED = (Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX);
+    int variant = loss_grad_variant();
+    if (variant < 0) variant = TUNED ? 7 : 4;
+    if (!TUNED && variant != 0) variant = 4;
+    if constexpr (TUNED) {
+        switch (variant) {
+            case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+            case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+            case 5: loss_grad_kernel<Lib, 5><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+            case 6: loss_grad_kernel<Lib, 6><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+            case 7: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+            case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+            default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+        }
+    } else {
+        if (variant == 4)
+            loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
+        else
+            loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
     }
     SYMODE_LAUNCH_CHECK();
     finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv_count, 2.0f * inv_count, loss,
