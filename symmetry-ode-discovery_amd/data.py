@@ -121,3 +121,70 @@ def make_dataset(name, n_ics, num_steps, dt=None, noise=0.0, seed=0, device="cpu
         std = x.std(dim=1, keepdim=True)
         x = x + noise * std * torch.randn(x.shape, generator=gen, device=device, dtype=x.dtype)
     return x.float().contiguous(), dx.float().contiguous()
+
+
+# -------------------------------------------------------------------------------------------------
+# Noisy-data recipe of the reference (data_utils/ode.py:30-49) with its two derivative estimators
+# -------------------------------------------------------------------------------------------------
+def gp_smooth(x, dt, noise_level, std_base, sigma_in, delta=1e-3):
+    """Gaussian-process smoothing and numerical differentiation of noisy trajectories
+    (reference data_utils/smoothing.py:155-196, ``num_diff_gp``).
+
+    x (T, n_traj, d) float64 on any device.  Per state dimension the reference builds a GP-PCA model with as many
+    factors as trajectories -- its loading matrix is then square and orthonormal, A A^T = I -- and takes the
+    predictive mean, which is ordinary GP regression with an RBF kernel shared by all trajectories:
+
+        X_hat(t*) = K(t*, t) (K(t, t) + sigma^2 I)^-1 Y,     K = sigma_out^2 exp(-(t - t')^2 / (2 sigma_in^2)),
+        sigma = noise_level * std_base[d],  sigma_out = std_base[d];
+
+    the derivative is the reference's forward difference of the predictive mean, (X_hat(t + delta) - X_hat(t)) / delta.
+    One Cholesky factorisation of the (T, T) system per dimension (fp64; rocSOLVER when x lives on the GPU: T = 10^4
+    takes about a second there, minutes with the reference's chain of dense numpy inverses).  Returns (dX, X_hat).
+    """
+    T = x.shape[0]
+    t = torch.arange(T, device=x.device, dtype=torch.float64) * dt
+    gap = t[:, None] - t[None, :]
+    eye = torch.eye(T, device=x.device, dtype=torch.float64)
+    xs, dxs = [], []
+    for k in range(x.shape[-1]):
+        so, sn = float(std_base[k]), float(noise_level * std_base[k])
+        K = (so * so) * torch.exp(gap.square() * (-1.0 / (2.0 * sigma_in ** 2)))
+        alpha = torch.cholesky_solve(x[:, :, k].to(torch.float64), torch.linalg.cholesky(K + (sn * sn) * eye))
+        mean = K @ alpha
+        ahead = ((so * so) * torch.exp((gap + delta).square() * (-1.0 / (2.0 * sigma_in ** 2)))) @ alpha
+        xs.append(mean)
+        dxs.append((ahead - mean) / delta)
+    return torch.stack(dxs, -1), torch.stack(xs, -1)
+
+
+def gen_data(name, n_ics, dt=0.002, num_steps=2000, subsample_rate=1, noise=0.0, multiplicative_noise=False, smoothing=None,
+             gp_sigma_in=0.1, seed=0, device="cpu", fused=None):
+    """One data set the way the reference's generators make it (data_utils/ode.py:30-49 behind
+    ``get_{dosc,lv,selkov,growth}_data``): RK4 orbits; noise relative to each dimension's standard deviation over
+    (time, trajectory) -- multiplicative for ``growth`` -- and then the derivative of the NOISY series: forward
+    differences (the last sample keeps the exact RHS), or ``smoothing='gp'``: ``gp_smooth`` replaces both x and dx.
+    Returns fp32 (n_ics, num_steps / subsample_rate, d) tensors x, dx on ``device``."""
+    rhs, ics, _ = SYSTEMS[name]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    x0 = ics(n_ics, gen, device)
+    if fused is None:
+        fused = torch.device(device).type == "cuda"
+    if fused:
+        x, dx = rk4_trajectories_fused(name, x0, dt, num_steps)
+    else:
+        x, dx = rk4_trajectories(rhs, x0, dt, num_steps)
+    x, dx = x.double().transpose(0, 1).contiguous(), dx.double().transpose(0, 1).contiguous()      # (T, n_ics, d)
+    if noise > 0:
+        std = x.std(dim=(0, 1), unbiased=False)
+        eps = torch.randn(x.shape, generator=gen, device=device, dtype=torch.float64)
+        x = x * (1 + eps * noise) if multiplicative_noise else x + eps * noise * std
+        if smoothing is None:
+            dx[:-1] = (x[1:] - x[:-1]) / dt
+        elif smoothing == "gp":
+            print("Smoothing with Gaussian process...")
+            dx, x = gp_smooth(x, dt, noise, std, gp_sigma_in)
+        else:
+            raise NotImplementedError(f"smoothing={smoothing!r}")
+    x, dx = x[::subsample_rate].transpose(0, 1), dx[::subsample_rate].transpose(0, 1)
+    return x.float().contiguous(), dx.float().contiguous()

@@ -4,8 +4,9 @@ Files: ``./data/{ode}-{mode}-noise{NN}[-{smoothing}]-{x,dx}.pt`` holding float32
 shape (n_ics, n_steps, d); the dataset flattens them to (n_ics*n_steps, d) points.  When the
 files are absent (the authors distribute them out of band) trajectories are synthesised with the
 RK4 restatement in data.py using the README recipe sizes, and written under ./data like the
-reference's fallback (dataset.py:178-186).  GP smoothing is not reproduced: synthesised noisy data
-keep the exact derivative of the clean orbit.
+reference's fallback (dataset.py:178-186), following its generators' recipe (data.gen_data): noise relative to each
+dimension's spread, then forward differences of the noisy series or, with ``--smoothing gp``, GP regression
+(data.gp_smooth = the reference's num_diff_gp, one Cholesky solve per dimension).
 
 Reaction-diffusion tasks (``rd``, ``mt_rd``; dataset.py:59-159) read ``./data/reaction_diffusion.mat`` (fields t, x, y,
 uf, duf -- the SINDy-autoencoder example file, distributed out of band) when it exists; otherwise a rigidly rotating
@@ -44,10 +45,11 @@ class ODEDataset(Dataset):
             print(f'Load data failed. Generating {ode_name} {mode} data...')
             n_tr, n_va, steps, sub, dt = _RECIPES[ode_name]
             n_ics = n_tr if 'train' in mode else n_va
-            xs, dxs = synth.make_dataset(ode_name, n_ics, steps, dt=dt, noise=noise, seed=0 if 'train' in mode else 1)
-            d = xs.shape[-1]
-            x = xs.reshape(n_ics, steps, d)[:, ::sub].contiguous()
-            dx = dxs.reshape(n_ics, steps, d)[:, ::sub].contiguous()
+            gen_dev = 'cuda' if torch.cuda.is_available() else 'cpu'      # HIP RK4 kernel + rocSOLVER for the GP solve
+            x, dx = synth.gen_data(ode_name, n_ics, dt=dt, num_steps=steps, subsample_rate=sub, noise=noise,
+                                   multiplicative_noise=(ode_name == 'growth'), smoothing=smoothing, gp_sigma_in=0.1,
+                                   seed=0 if 'train' in mode else 1, device=gen_dev)
+            x, dx = x.cpu(), dx.cpu()
             os.makedirs(path, exist_ok=True)
             torch.save(x, f'{stem}-x.pt')
             torch.save(dx, f'{stem}-dx.pt')

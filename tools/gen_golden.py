@@ -48,6 +48,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     from evaluation import eval_eq as ref_eval
     from data_utils import damped_oscillator as ref_dosc, selkov as ref_selkov, lotka as ref_lv, growth as ref_growth
     from data_utils import ode as ref_ode
+    from data_utils import smoothing as ref_smoothing
 
 
 def quiet(fn, *a, **k):
@@ -543,8 +544,24 @@ def f9_lassi():
     save("f9_lassi", **arrays)
 
 
+def f10_gp_smoothing():
+    """N4: ``num_diff_gp`` (data_utils/smoothing.py:155-196) on short noisy damped-oscillator and Lotka-Volterra series."""
+    arrays = {}
+    for tag, fn, init, T, dt, noise, sig_in in (("dosc", ref_dosc.dosc, ref_dosc.generate_random_ics, 150, 0.02, 0.2, 0.1),
+                                                ("lv", ref_lv.lotka_volterra, None, 120, 0.01, 0.5, 0.05)):
+        np.random.seed(1010)
+        x0 = init(5) if init is not None else np.random.uniform(-0.5, 0.5, (5, 2))
+        x, _ = quiet(ref_ode.solve_ode_batch, fn, x0, dt=dt, num_steps=T)
+        std = np.std(x, axis=(0, 1))
+        x = x + np.random.randn(*x.shape) * noise * std
+        dX, X = quiet(ref_smoothing.num_diff_gp, x.copy(), dt, noise_level=noise, std_base=std, sigma_in=sig_in)
+        arrays.update({f"{tag}_x": x, f"{tag}_std": std, f"{tag}_dt": np.array(dt), f"{tag}_noise": np.array(noise),
+                       f"{tag}_sigma_in": np.array(sig_in), f"{tag}_dX": dX, f"{tag}_X": X})
+    save("f10_gp_smoothing", **arrays)
+
+
 ALL = {"f1": f1_theta, "f2": f2_fwd_loss_grad, "f3": f3_stlsq, "f4": f4_lbfgs, "f5": f5_constraint,
-       "f6": f6_symreg, "f7": f7_wsindy, "f8": f8_known_answers, "f9": f9_lassi}
+       "f6": f6_symreg, "f7": f7_wsindy, "f8": f8_known_answers, "f9": f9_lassi, "f10": f10_gp_smoothing}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
