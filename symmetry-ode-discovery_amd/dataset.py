@@ -32,6 +32,40 @@ _RECIPES = {'dosc': (50, 10, 10000, 100, 0.002), 'growth': (100, 20, 1000, 10, 0
             'lv': (200, 20, 10000, 1, 0.002), 'selkov': (10, 5, 10000, 1, 0.002)}
 
 
+class DeviceBatches:
+    """Drop-in for ``DataLoader(dataset, batch_size, shuffle)`` over an in-memory data set: the arrays are moved to
+    ``device`` once and every batch is ONE index gather there (a fresh permutation per epoch when shuffling, last
+    batch short), instead of batch_size Python ``__getitem__`` calls + collation + an H2D copy per batch -- which is
+    what bounds the reference's loaders at batch sizes like 8192 (70 ms per batch for the multi-timestep LV set).
+    ``window`` > 0: item i is rows i .. i+window-1 (the multi-timestep reaction-diffusion layout)."""
+
+    def __init__(self, arrays, n_items, batch_size, shuffle, device, window=0, limit_bytes=8 << 30):
+        total = sum(a.numel() * a.element_size() for a in arrays)
+        self.arrays = [a.to(device) if total <= limit_bytes else a.pin_memory() for a in arrays]
+        self.device, self.n, self.bs, self.shuffle, self.window = device, n_items, batch_size, shuffle, window
+
+    def __len__(self):
+        return (self.n + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        dev = self.arrays[0].device
+        order = torch.randperm(self.n, device=dev) if self.shuffle else torch.arange(self.n, device=dev)
+        for lo in range(0, self.n, self.bs):
+            idx = order[lo:lo + self.bs]
+            if self.window:
+                idx = idx[:, None] + torch.arange(self.window, device=dev)[None, :]
+            yield tuple(a[idx].to(self.device, non_blocking=True) for a in self.arrays)
+
+
+def make_loader(dataset, batch_size, shuffle, device):
+    """``DeviceBatches`` for the in-memory data sets of this module, ``DataLoader`` for anything else."""
+    if str(device) != 'cpu' and hasattr(dataset, 'device_arrays'):
+        arrays, n_items, window = dataset.device_arrays()
+        return DeviceBatches(arrays, n_items, batch_size, shuffle, device, window)
+    from torch.utils.data import DataLoader
+    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle)
+
+
 class ODEDataset(Dataset):
     def __init__(self, path=data_path, ode_name='lv', mode='train', noise=0.0, smoothing=None):
         super().__init__()
@@ -64,6 +98,9 @@ class ODEDataset(Dataset):
     def __getitem__(self, idx):
         return self.x[idx], self.dx[idx]
 
+    def device_arrays(self):
+        return [self.x, self.dx], len(self.x), 0
+
 
 class MTODEDataset(Dataset):
     """Windows of ``n_timesteps`` states, ``interval`` samples apart, along every trajectory
@@ -87,6 +124,9 @@ class MTODEDataset(Dataset):
 
     def __getitem__(self, idx):
         return self.x[idx], self.dx[idx]
+
+    def device_arrays(self):
+        return [self.x, self.dx], len(self.x), 0
 
 
 # synthetic stand-in for reaction_diffusion.mat: grid points per side, snapshots, time step (ode_dt_dict['rd']),
@@ -154,6 +194,9 @@ class MultiTimestepReactionDiffusionDataset(Dataset):
 
     def __getitem__(self, idx):
         return self.x[idx:idx + self.n_timesteps], self.dx[idx:idx + self.n_timesteps]
+
+    def device_arrays(self):
+        return [self.x, self.dx], len(self), self.n_timesteps
 
 
 def get_dataset(args):

@@ -13,11 +13,10 @@ import os
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
 
 from . import train as T
 from .autoencoder import AutoEncoder
-from .dataset import get_dataset
+from .dataset import get_dataset, make_loader
 from .evaluation import eval_sindy_regressor, sindy_truth
 from .lie import Discriminator, LieGenerator
 from .parser_utils import get_args
@@ -35,12 +34,13 @@ def main(argv=None):
         raise SystemExit('symode_amd runs the SINDy path on the GPU only (no CPU fallback): a HIP device is required')
 
     train_dataset, val_dataset, args = get_dataset(args)
+    # DataLoader semantics (main.py:33-39), served from device-resident arrays: one gather per batch
     if args['sindy_optimizer'] != 'lbfgs':
-        train_loader = DataLoader(train_dataset, batch_size=args['batch_size'], shuffle=True)
+        train_loader = make_loader(train_dataset, args['batch_size'], True, args['device'])
     else:
         data_size = int(len(train_dataset) * args['lbfgs_subsample'])
-        train_loader = DataLoader(train_dataset, batch_size=data_size, shuffle=True)
-    val_loader = DataLoader(val_dataset, batch_size=args['batch_size'], shuffle=False)
+        train_loader = make_loader(train_dataset, data_size, True, args['device'])
+    val_loader = make_loader(val_dataset, args['batch_size'], False, args['device'])
 
     autoencoder = AutoEncoder(**args).to(args['device'])
     discriminator = Discriminator(**args).to(args['device'])

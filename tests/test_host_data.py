@@ -56,3 +56,27 @@ def test_ode_dataset_fallback_honours_smoothing(tmp_path, monkeypatch):
     assert (ds.dx - truth).abs().mean() < 0.25 * (raw.dx - clean_dx_full(raw.x)).abs().mean()
     again = D.ODEDataset(path=str(tmp_path), ode_name="dosc", mode="train", noise=0.2, smoothing="gp")    # now from the files
     assert torch.equal(again.x, ds.x)
+
+
+def test_device_batches_serve_dataloader_semantics(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setitem(D.RD_SYNTH, "n", 6)
+    monkeypatch.setitem(D.RD_SYNTH, "n_samples", 40)
+    np.random.seed(0)
+    mt = D.MultiTimestepReactionDiffusionDataset(mode="train")
+    arrays, n, window = mt.device_arrays()
+    fast = D.DeviceBatches(arrays, n, batch_size=7, shuffle=False, device="cpu", window=window)
+    slow = torch.utils.data.DataLoader(mt, batch_size=7, shuffle=False)
+    assert len(fast) == len(slow) == 5
+    for (a, b), (c, d) in zip(fast, slow):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    torch.manual_seed(0)
+    shuffled = D.DeviceBatches(arrays, n, batch_size=7, shuffle=True, device="cpu", window=window)
+    seen = torch.cat([a[:, 0, :1] for a, _ in shuffled]).flatten()
+    assert sorted(seen.tolist()) == sorted(mt.x[:n, 0].tolist()) and not torch.equal(seen, mt.x[:n, 0])   # a permutation of every item
+    monkeypatch.setitem(D._RECIPES, "dosc", (3, 2, 200, 2, 0.005))
+    ds = D.ODEDataset(path=str(tmp_path), ode_name="dosc", mode="train", noise=0.0)
+    assert isinstance(D.make_loader(ds, 64, True, "cpu"), torch.utils.data.DataLoader)                        # host runs keep DataLoader
+    fb = D.DeviceBatches(*ds.device_arrays()[:1], ds.device_arrays()[1], 128, False, "cpu")
+    x0, dx0 = next(iter(fb))
+    assert torch.equal(x0, ds.x[:128]) and torch.equal(dx0, ds.dx[:128]) and len(fb) == 3
