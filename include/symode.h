@@ -74,6 +74,12 @@ int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, i
 int symode_odeint(const float* x, long n, int d, int order, int flags, const float* xi, const float* mask,
                   int n_steps, float dt, int method, float* out, void* stream);
 
+/* Same integration, every intermediate state kept: traj (n_steps, n, d), traj[s] = state after step s+1.
+ * replaces: odeint(regressor, x0, t, dt, method, full_traj=True), model_utils.py:249-254 -- the long-term
+ * prediction roll-out of evaluation/eval_ltp.py:31-37 (n_steps sequential Theta builds + GEMMs there). */
+int symode_odeint_traj(const float* x, long n, int d, int order, int flags, const float* xi, const float* mask,
+                       int n_steps, float dt, int method, float* traj, void* stream);
+
 /* Augmented Gram matrix in fp64 (MFMA f64): A = [Theta(x) | dx] (n, p+d),
  *   gram_out[s] (p+d, p+d) = A^T A   (row-major, both triangles filled).
  * Every quantity of the ridge-augmented least-squares solve (sindy.py:261-288) and of the

@@ -112,6 +112,16 @@ int symode_odeint(const float* x, long n, int d, int order, int flags, const flo
     return (int)ops->odeint(x, n, xi, mask, n_steps, dt, method, out, (hipStream_t)stream);
 }
 
+int symode_odeint_traj(const float* x, long n, int d, int order, int flags, const float* xi, const float* mask, int n_steps,
+                       float dt, int method, float* traj, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 0 || n_steps < 0 || (method != 0 && method != 1)) return SYMODE_E_BADSIZE;
+    if (n == 0 || n_steps == 0) return SYMODE_OK;
+    if (!x || !xi || !traj) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(traj, 4) || misaligned(xi, 4) || misaligned(mask, 4)) return SYMODE_E_ALIGN;
+    return (int)ops->odeint_traj(x, n, xi, mask, n_steps, dt, method, traj, (hipStream_t)stream);
+}
+
 int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, int d, int order, int flags,
                      const float* xi, const float* mask, float inv_count, float* loss_out, float* grad_out,
                      void* workspace, size_t workspace_bytes, void* stream) {

@@ -30,6 +30,8 @@ struct LibOps {
     hipError_t (*forward)(const float* x, long n, const float* xi, const float* mask, float* out, hipStream_t st);
     hipError_t (*odeint)(const float* x, long n, const float* xi, const float* mask, int n_steps, float dt, int method,
                          float* out, hipStream_t st);
+    hipError_t (*odeint_traj)(const float* x, long n, const float* xi, const float* mask, int n_steps, float dt, int method,
+                              float* traj, hipStream_t st);
     hipError_t (*loss_grad)(const float* x, const float* dx, long S, long n, const float* xi, const float* mask,
                             float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st);
     hipError_t (*symreg_linear)(const float* z, long n, const float* xi, const float* mask, const float* L, int n_gen,
@@ -194,9 +196,9 @@ __global__ __launch_bounds__(BLOCK) void forward_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------
 // fixed-step integrator: K Euler / RK4 steps of dx/dt = Theta(x) Xi_m^T   (odeint)
 // ---------------------------------------------------------------------------------------
-template <class Lib>
-__device__ __forceinline__ void integrate(const float (&w)[Lib::D * Lib::P], float (&x)[Lib::D], int n_steps, float dt,
-                                          int method) {
+template <class Lib, class OnStep>
+__device__ __forceinline__ void integrate_steps(const float (&w)[Lib::D * Lib::P], float (&x)[Lib::D], int n_steps, float dt,
+                                                int method, OnStep on_step) {
     constexpr int D = Lib::D;
     if (method == 0) {
         for (int s = 0; s < n_steps; ++s) {
@@ -204,6 +206,7 @@ __device__ __forceinline__ void integrate(const float (&w)[Lib::D * Lib::P], flo
             rhs<Lib>(w, x, h);
 #pragma unroll
             for (int j = 0; j < D; ++j) x[j] = x[j] + dt * h[j];               // model_utils.py:238
+            on_step(s, x);
         }
     } else {
         for (int s = 0; s < n_steps; ++s) {                                    // model_utils.py:242-247
@@ -220,7 +223,32 @@ __device__ __forceinline__ void integrate(const float (&w)[Lib::D * Lib::P], flo
             rhs<Lib>(w, y, k4);
 #pragma unroll
             for (int j = 0; j < D; ++j) x[j] = x[j] + dt / 6 * (k1[j] + 2 * k2[j] + 2 * k3[j] + k4[j]);
+            on_step(s, x);
         }
+    }
+}
+
+template <class Lib>
+__device__ __forceinline__ void integrate(const float (&w)[Lib::D * Lib::P], float (&x)[Lib::D], int n_steps, float dt,
+                                          int method) {
+    integrate_steps<Lib>(w, x, n_steps, dt, method, [](int, const float (&)[Lib::D]) {});
+}
+
+// Full trajectory (odeint(..., full_traj=True), model_utils.py:249-254): a thread per initial state, the state after
+// every step written to traj[step][point][:] -- consecutive lanes write consecutive points (coalesced).
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void odeint_traj_kernel(const float* __restrict__ x, long N, const float* __restrict__ xi,
+                                                            const float* __restrict__ mask, int n_steps, float dt, int method,
+                                                            float* __restrict__ traj) {
+    constexpr int D = Lib::D;
+    float w[D * Lib::P];
+    load_xi<Lib>(xi, mask, 0, w);
+    for (long n = (long)blockIdx.x * BLOCK + threadIdx.x; n < N; n += (long)gridDim.x * BLOCK) {
+        float xp[D];
+        load_point<D>(x, n, xp);
+        integrate_steps<Lib>(w, xp, n_steps, dt, method, [&](int s, const float (&cur)[D]) {
+            store_point<D>(traj + (long)s * N * D, n, cur);
+        });
     }
 }
 
@@ -1126,6 +1154,16 @@ hipError_t launch_forward(const float* x, long n, const float* xi, const float* 
     const int g = grid_x_for(n, 1, Chunk<Lib::D>::PPT);
     const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(out, n, Lib::D, 1);
     forward_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, n, vec, xi, mask, out);
+    SYMODE_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <class Lib>
+hipError_t launch_odeint_traj(const float* x, long n, const float* xi, const float* mask, int n_steps, float dt, int method,
+                              float* traj, hipStream_t st) {
+    long g = (n + BLOCK - 1) / BLOCK;
+    if (g > 4096) g = 4096;
+    odeint_traj_kernel<Lib><<<dim3((unsigned)g), dim3(BLOCK), 0, st>>>(x, n, xi, mask, n_steps, dt, method, traj);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }

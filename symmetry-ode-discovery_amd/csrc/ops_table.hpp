@@ -15,6 +15,7 @@ constexpr LibOps make_ops() {
                   &launch_theta<Lib>,
                   &launch_forward<Lib>,
                   &launch_odeint<Lib>,
+                  &launch_odeint_traj<Lib>,
                   &launch_loss_grad<Lib>,
                   &launch_symreg_linear<Lib>,
                   &launch_symreg_reversed<Lib>,

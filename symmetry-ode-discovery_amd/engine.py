@@ -29,6 +29,8 @@ _SIGNATURES = {
     "symode_forward": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "symode_odeint": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
                               c_void_p, c_void_p]),
+    "symode_odeint_traj": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
+                              c_void_p, c_void_p]),
     "symode_loss_grad": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_aug_gram": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
@@ -162,6 +164,22 @@ class HipEngine:
         self._check(self.lib.symode_odeint(self._ptr(x), n, d, order, flags, self._ptr(xi), self._ptr(mask), int(n_steps),
                                            float(dt), m, self._ptr(out), self._stream(x)), "symode_odeint")
         return out
+
+    def odeint_traj(self, x, xi, mask, order, flags, n_steps, dt, method="euler"):
+        """(n_steps, n, d): the state after every step (odeint(..., full_traj=True))."""
+        x = self._dev(x, "x")
+        d = x.shape[-1]
+        n = x.numel() // d
+        xi = self._dev(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        self._check_coef(xi, mask, d, order, flags)
+        m = {"euler": 0, "rk4": 1}.get(method)
+        if m is None:
+            raise ValueError("Unrecognized ODEInt method.")
+        traj = torch.empty(int(n_steps), n, d, dtype=torch.float32, device=x.device)
+        self._check(self.lib.symode_odeint_traj(self._ptr(x), n, d, order, flags, self._ptr(xi), self._ptr(mask), int(n_steps),
+                                                float(dt), m, self._ptr(traj), self._stream(x)), "symode_odeint_traj")
+        return traj
 
     def _check_coef(self, xi, mask, d, order, flags, n_problems=1):
         p = self.lib_size(d, order, flags)

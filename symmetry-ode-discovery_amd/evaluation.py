@@ -79,3 +79,33 @@ def aggregate_results(run_name, min_seed=0, max_seed=100, mse_multiplier=1.0):
     print(f"All equations RMSE = {out['rmse_all'][0]:.4f} ({out['rmse_all'][1]:.4f})")
     print(f"All equations RMSE (any) = {out['rmse_all_any'][0]:.4f} ({out['rmse_all_any'][1]:.4f})")
     return out
+
+
+@torch.no_grad()
+def eval_ltp_accuracy(regressor, autoencoder, x, dt=None, **kwargs):
+    """Long-term prediction with the learned dynamics (reference evaluation/eval_ltp.py:9-45): roll the regressor's
+    ODE out from x[:, 0] with RK4 over the length of x (through the autoencoder's latent space when one is given)
+    and report the squared error per step.  x: (n_ics, n_steps, d) or (n_ics, n_steps, n_comps, d).
+    The roll-out is ONE launch of the fused full-trajectory integrator (symode_odeint_traj)."""
+    from .dataset import ode_dt_dict
+    from .model_utils import odeint
+    x0 = x[:, 0]
+    if x.dim() == 3:
+        n_ics, n_steps, n_dim = x.shape
+    else:
+        n_ics, n_steps, _, n_dim = x.shape
+    n_steps -= 1
+    if dt is None:
+        dt = ode_dt_dict[kwargs['task'].split('_')[-1]]
+    t_max = n_steps * dt
+    if autoencoder is not None:
+        z0 = autoencoder.encode(x0)
+        if z0.dim() == 3:
+            z0 = z0.flatten(0, 1)
+        z_pred = odeint(regressor, z0, t_max, dt, method='rk4', full_traj=True).transpose(0, 1)
+        x_pred = autoencoder.decode(z_pred.flatten(0, 1)).reshape(n_ics, n_steps, n_dim)
+    else:
+        x_pred = odeint(regressor, x0, t_max, dt, method='rk4', full_traj=True).transpose(0, 1)
+    error = torch.mean((x[:, 1:] - x_pred) ** 2, dim=-1)
+    res = {'x_pred': x_pred, 't': torch.arange(1, n_steps + 1) * dt, 'error': error}
+    return {k: v.cpu().numpy() for k, v in res.items()}

@@ -27,18 +27,22 @@ def odeint(f, x0, t, dt, method='euler', full_traj=False):
     '''
     Integrate an ODE f over a time interval differentiably (fixed step).
     f: nn.Module / callable RHS;  x0: initial state;  t: time;  dt: step;  method: 'euler' | 'rk4'.
-    A SINDyRegression RHS with no gradient requested and no trajectory wanted runs as ONE fused
-    kernel (all K steps in registers); otherwise the steps are chained through autograd.
+    A SINDyRegression RHS with no gradient requested runs as ONE fused kernel (all K steps in registers;
+    ``full_traj`` writes the state after every step); otherwise the steps are chained through autograd.
     '''
     n_steps = int(t / dt)
     if method not in ('euler', 'rk4'):
         raise ValueError('Unrecognized ODEInt method.')
-    fused = (isinstance(f, SINDyRegression) and not full_traj and x0.is_cuda
+    fused = (isinstance(f, SINDyRegression) and x0.is_cuda
              and not (torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in f.parameters()))))
     if fused:
         xi = f.get_Xi().detach()
         lead = x0.shape[:-1]
-        out = f.engine.odeint(x0.reshape(-1, f.latent_dim), xi, f.mask, f.poly_order, f.flags, n_steps, dt, method)
+        flat = x0.reshape(-1, f.latent_dim)
+        if full_traj:                                       # (K, ..., d): every step of the roll-out from ONE launch
+            out = f.engine.odeint_traj(flat, xi, f.mask, f.poly_order, f.flags, n_steps, dt, method)
+            return out.reshape(n_steps, *lead, f.latent_dim)
+        out = f.engine.odeint(flat, xi, f.mask, f.poly_order, f.flags, n_steps, dt, method)
         return out.reshape(*lead, f.latent_dim)
     traj = []
     for _ in range(n_steps):

@@ -168,6 +168,29 @@ def test_odeint_golden(eng, golden, tag):
     assert torch.equal(eng.odeint(x, Xi, mask, order, fl, 0, dt), x)
 
 
+@pytest.mark.parametrize("d,order,fl,method", [(2, 3, 0, "rk4"), (2, 2, 2, "rk4"), (2, 5, 0, "euler"), (3, 2, 1, "rk4"), (1, 3, 0, "euler"), (4, 2, 0, "rk4")])
+def test_odeint_full_trajectory_vs_oracle_steps(eng, d, order, fl, method):
+    """symode_odeint_traj: the state after EVERY step equals the oracle's chained fp32 steps (odeint(..., full_traj=True));
+    its last row is what symode_odeint returns."""
+    torch.manual_seed(d * 10 + order)
+    n, K, dt = 333, 40, 0.02
+    p = O.term_count(d, order, bool(fl & 1), bool(fl & 2))
+    x, Xi = (torch.randn(n, d) * 0.3).clamp(-0.6, 0.6), torch.randn(d, p) * 0.2
+    mask = (torch.rand(d, p) > 0.3).float()
+    for j in range(d):                                          # linear damping keeps every orbit bounded over the window
+        Xi[j, 1 + j], mask[j, 1 + j] = -1.0, 1.0
+    f = lambda a: O.forward(a, Xi, mask, order, bool(fl & 1), bool(fl & 2))  # noqa: E731
+    want = O.odeint(f, x, K * dt + 0.5 * dt, dt, method, full_traj=True)
+    assert want.abs().max() < 2.0
+    got = eng.odeint_traj(x.cuda(), Xi.cuda(), mask.cuda(), order, fl, K, dt, method)
+    assert got.shape == (K, n, d)
+    # 40 chained steps of a random polynomial field: rounding differences of the p-term sums grow along the orbit
+    assert np.allclose(got.cpu().numpy(), want.numpy(), rtol=3e-4, atol=2e-5)
+    assert np.allclose(got[:5].cpu().numpy(), want[:5].numpy(), rtol=2e-5, atol=2e-6)
+    assert torch.equal(got[-1], eng.odeint(x.cuda(), Xi.cuda(), mask.cuda(), order, fl, K, dt, method))
+    assert eng.odeint_traj(x.cuda(), Xi.cuda(), mask.cuda(), order, fl, 0, dt, method).shape == (0, n, d)
+
+
 # ------------------------------------------------------------------------------------ gram
 @pytest.mark.parametrize("d,order,fl", [(2, 2, 0), (2, 3, 0), (2, 5, 0), (2, 2, 2), (3, 3, 0), (1, 4, 3), (4, 3, 0), (3, 4, 1)])
 @pytest.mark.parametrize("n", [1, 63, 256, 257, 5000])

@@ -183,3 +183,32 @@ def test_lstsq_residual_is_differentiable_wrt_data(S):
         assert np.isclose(res.item(), want.item(), rtol=1e-4)
         assert torch.allclose(dz.grad.cpu().double(), dzr.grad, rtol=1e-3, atol=1e-5 * dzr.grad.abs().max().item())
         assert torch.allclose(z.grad.cpu().double(), zr.grad, rtol=1e-3, atol=1e-4 * zr.grad.abs().max().item())
+
+
+def test_eval_ltp_accuracy_rollout_matches_chained_steps():
+    """evaluation.eval_ltp_accuracy (reference eval_ltp.py): RK4 roll-out of the learned model from x[:, 0] -- the fused
+    full-trajectory kernel against the oracle's step-by-step fp32 integration, with and without an autoencoder."""
+    import symode_amd
+    from symode_amd.evaluation import eval_ltp_accuracy
+    x, _ = symode_amd.data.gen_data("dosc", 6, dt=0.2, num_steps=60, seed=1, device="cuda:0")
+    r = symode_amd.SINDyRegression(2, 2, False, False, threshold=0.05, device="cuda:0")
+    Xi = torch.tensor([[0.0, -0.11, -0.97, 0.0, 0.01, 0.0], [0.0, 1.02, -0.1, 0.0, 0.0, -0.01]])
+    r.Xi.data = Xi.cuda()
+    res = eval_ltp_accuracy(r, None, x, task="dosc")
+    assert res["x_pred"].shape == (6, 59, 2) and res["error"].shape == (6, 59) and np.allclose(res["t"], np.arange(1, 60) * 0.2)
+    f = lambda a: O.forward(a, Xi, torch.ones(2, 6), 2)  # noqa: E731
+    want = O.odeint(f, x[:, 0].cpu(), 59 * 0.2, 0.2, "rk4", full_traj=True).transpose(0, 1)
+    assert np.allclose(res["x_pred"], want.numpy(), rtol=1e-4, atol=1e-5)
+    assert np.allclose(res["error"], ((x[:, 1:].cpu() - want) ** 2).mean(-1).numpy(), rtol=1e-3, atol=1e-7)
+    assert res["error"][:, :5].max() < 1e-2                      # a near-true model tracks the orbit at first
+
+    class Scale(torch.nn.Module):                                # a linear "autoencoder": z = 2 x
+        def encode(self, a):
+            return 2.0 * a
+
+        def decode(self, z):
+            return 0.5 * z
+    r2 = symode_amd.SINDyRegression(2, 2, False, False, threshold=0.05, device="cuda:0")
+    r2.Xi.data = torch.tensor([[0.0, -0.11, -0.97, 0.0, 0.005, 0.0], [0.0, 1.02, -0.1, 0.0, 0.0, -0.005]]).cuda()   # same ODE in z = 2x
+    res2 = eval_ltp_accuracy(r2, Scale(), x, task="mt_dosc")
+    assert np.allclose(res2["x_pred"], res["x_pred"], rtol=1e-3, atol=1e-4)
