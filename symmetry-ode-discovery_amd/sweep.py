@@ -218,6 +218,8 @@ class SeedSweepLBFGS:
         c = self.c
         a, b = self._split(P)
         loss, ga, gb = c.evaluate(a.contiguous(), b, mask=self.mask)
+        if gb is None and c.Q is not None:                                  # constrain_constant: const is a parameter the
+            gb = torch.zeros(c.S, c.d, 1, device=P.device, dtype=P.dtype)   # model does not read (sindy.py:60, 173-175)
         g = ga.reshape(c.S, -1) if gb is None else torch.cat([ga, gb.reshape(c.S, -1)], dim=1)
         loss, g = self.w_x * loss, self.w_x * g
         if self.reg_type == "l1":                                           # over the raw parameters (train.py:681)

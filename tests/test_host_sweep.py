@@ -84,3 +84,27 @@ def test_lbfgs_sweep_matches_sequential_runs_constrained(golden):
         assert torch.equal(out["mask"][s], reg.mask), s
         want = (reg.get_Xi() * reg.mask).detach().numpy()
         assert np.allclose((out["Xi"][s] * out["mask"][s]).numpy(), want, rtol=2e-3, atol=2e-4), s
+
+
+def test_lbfgs_sweep_with_constrained_constant_matches_sequential_runs():
+    """growth/noise05_esindy flags: scaling2 constraint with --constrain_constant, i.e. ``const`` stays a parameter that the
+    model never reads (sindy.py:60, 173-175): its gradient is zero and it must not break the flat parameter layout."""
+    xs, dxs = O.rk4_trajectories(O.rhs_growth, O.ics_growth(6, np.random.RandomState(4)), 0.02, 150)
+    x, dx = torch.from_numpy(xs.reshape(-1, 2)).float(), torch.from_numpy(dxs.reshape(-1, 2)).float()
+    scaling2 = torch.tensor([[2.0, 0.0], [0.0, 1.0]])
+    Q, use_kron = constraint_Q([scaling2], 2, 2)
+    torch.manual_seed(5)
+    inits = torch.randn(3, Q.shape[1] + 2)
+    S = inits.shape[0]
+    clos = BatchedClosure(x.expand(S, -1, -1).contiguous(), dx.expand(S, -1, -1).contiguous(), 2, Q=Q, use_kron_product=use_kron,
+                          allow_constant=False, engine=OracleEngine())
+    out = SeedSweepLBFGS(clos, 1.0, 0.05, 100).fit(inits, 40)
+    truth = O.SINDY_TRUTH["growth"] != 0
+    for s in range(S):
+        reg = O.OracleRegressor(2, 2, L_list=[scaling2], threshold=0.05, constrain_constant=True, beta0=inits[s, :Q.shape[1]],
+                                const0=inits[s, Q.shape[1]:].view(2, 1))
+        O.lbfgs_fit(reg, x, dx, 40, 1.0, st_freq=100, threshold=0.05)
+        assert torch.equal(out["mask"][s], reg.mask), s
+        assert np.allclose((out["Xi"][s] * out["mask"][s]).numpy(), (reg.get_Xi() * reg.mask).detach().numpy(), rtol=2e-3, atol=2e-4), s
+        assert torch.equal(out["params"][s, Q.shape[1]:], inits[s, Q.shape[1]:])      # the unread constant never moves
+    assert np.array_equal(out["mask"][0].numpy() > 0, truth)
