@@ -65,6 +65,9 @@ def parse():
                     help="N > 1: 'points' = every rank holds a shard of each problem's trajectories and the packed "
                          "[loss|grad] partials are all-reduced (RCCL, default); 'seeds' = every rank owns whole problems, "
                          "no data-path collective")
+    ap.add_argument("--rehearse_gloo", action="store_true",
+                    help="N > 1 rehearsal on a ONE-GPU box: every rank uses cuda:0 and the collectives go through gloo "
+                         "(exercises the sharded code path; the number it prints is not a scaling measurement)")
     ap.add_argument("--force_dist", action="store_true",
                     help="initialise the RCCL process group and run the collective path even with one rank (self-test)")
     ap.add_argument("--profile", action="store_true",
@@ -100,6 +103,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.rehearse_gloo:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or a.force_dist
@@ -107,7 +112,10 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         with _StdoutToStderr():
-            dist.init_process_group("nccl", device_id=dev)
+            if a.rehearse_gloo:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)                      # creates the RCCL communicator (banner goes to stderr)
             torch.cuda.synchronize()
