@@ -1,13 +1,19 @@
-"""Seed sweep of an equation-discovery config in ONE process (the reference runs
+"""Seed sweep of an equation-discovery config in ONE process per GPU (the reference runs
 ``for i in {0..49}; do python main.py --seed $i --config ...; done``, run_scripts/*.sh).
 
     python -m symode_amd.main_sweep --config dosc/sindy_lbfgs.cfg --seed 0 --n_seeds 50
+    python -m symode_amd.main_sweep --config selkov/sindy_lbfgs.cfg --n_seeds 64 --method stlsq
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m symode_amd.main_sweep \
+        --config selkov/sindy_lbfgs.cfg --n_seeds 64 --method stlsq          # BASELINE config 3: 8 x MI355X
 
 Every seed gets its own initial coefficients and its own ``--lbfgs_subsample`` draw of the data set
-(main.py:36-38); all seeds are optimised in lockstep by sweep.SeedSweepLBFGS on the batched fused
-closure, and each seed leaves the reference's ``eval_results/<save_dir>/seed{n}.npz`` so that
-``evaluation.aggregate_results`` works unchanged.  Plain / constrained L-BFGS SINDy only (no
-autoencoder terms).
+(main.py:36-38).  ``--method lbfgs`` (default): all seeds are optimised in lockstep by sweep.SeedSweepLBFGS on
+the batched fused closure.  ``--method stlsq``: sequential-threshold least squares per seed (train.py:872-887) from
+ONE gather-Gram launch over the (seed, point) index table (sweep.SeedSweepSTLSQ).  Under ``torch.distributed``
+(one process per GPU, backend nccl = RCCL over xGMI) every rank holds a contiguous block of trajectories; the per-seed
+``[loss | grad]`` vectors / Gram matrices are all-reduced and every rank takes identical decisions; rank 0 writes the
+reference's ``eval_results/<save_dir>/seed{n}.npz`` so that ``evaluation.aggregate_results`` works unchanged.
+Plain / constrained SINDy only (no autoencoder terms).
 """
 from __future__ import annotations
 
@@ -16,6 +22,7 @@ import sys
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from .batched import BatchedClosure
 from .dataset import get_dataset
@@ -23,26 +30,91 @@ from .evaluation import aggregate_results, sindy_truth
 from .lie import LieGenerator
 from .parser_utils import get_args
 from .sindy import SINDyRegression
-from .sweep import SeedSweepLBFGS
+from .sweep import SeedSweepLBFGS, SeedSweepSTLSQ
 
 
-def main(argv=None):
-    argv = list(sys.argv[1:] if argv is None else argv)
-    n_seeds = 50
-    if "--n_seeds" in argv:
-        i = argv.index("--n_seeds")
-        n_seeds = int(argv[i + 1])
+def _pop(argv, flag, default, cast):
+    if flag in argv:
+        i = argv.index(flag)
+        value = cast(argv[i + 1])
         del argv[i:i + 2]
+        return value
+    return default
+
+
+def _write_results(args, seeds, Xi, mask, truth):
+    """eval_results/<save_dir>/seed{n}.npz per seed (evaluation/eval_eq.py:7-34, main.py:128-138)."""
+    eval_dir = f'eval_results/{args["save_dir"]}'
+    os.makedirs(eval_dir, exist_ok=True)
+    tmask = truth != 0
+    for k, s in enumerate(seeds):
+        coef = np.where(mask[k], Xi[k], 0.0)
+        cf = np.array([float(np.all(mask[k, i] == tmask[i])) for i in range(truth.shape[0])])
+        mse = np.array([np.mean((coef[i, tmask[i]] - truth[i, tmask[i]]) ** 2) for i in range(truth.shape[0])])
+        np.savez(f'{eval_dir}/seed{s}.npz', coefficients=coef, correct_form=cf, mse=mse, correct_form_all=np.all(cf),
+                 mse_all=np.mean(mse))
+
+
+def main(argv=None, engine=None, backend='nccl'):
+    """``engine`` / ``backend`` exist for the CPU rehearsal of the multi-rank path in tests (gloo + the test engine)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    n_seeds = _pop(argv, '--n_seeds', 50, int)
+    method = _pop(argv, '--method', 'lbfgs', str)
+    if method not in ('lbfgs', 'stlsq'):
+        raise SystemExit(f'--method {method}: lbfgs or stlsq')
     args = vars(get_args(argv=argv))
-    if str(args['device']) == 'cpu':
-        raise SystemExit('symode_amd runs the SINDy path on the GPU only (no CPU fallback): a HIP device is required')
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if engine is None:
+        if str(args['device']) == 'cpu':
+            raise SystemExit('symode_amd runs the SINDy path on the GPU only (no CPU fallback): a HIP device is required')
+        if world > 1:
+            local = int(os.environ.get('LOCAL_RANK', '0'))
+            torch.cuda.set_device(local)
+            args['device'] = torch.device('cuda', local)
     if args['sindy_optimizer'] != 'lbfgs' or args['use_latent'] or args['w_sym_reg'] > 0:
         raise SystemExit('main_sweep covers the L-BFGS SINDy / EquivSINDy-c configs (no latent / symmetry-regulariser terms)')
     dev = args['device']
-    train_dataset, _, args = get_dataset(args)
-    x_all, dx_all = train_dataset.x.to(dev), train_dataset.dx.to(dev)
-    m = int(len(train_dataset) * args['lbfgs_subsample'])
+    group = None
+    if world > 1:
+        if not dist.is_initialized():
+            dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+        group = dist.group.WORLD
+        if rank == 0:                                               # one rank makes the data files, the others read them
+            train_dataset, _, args = get_dataset(args)
+        dist.barrier()
+        if rank != 0:
+            train_dataset, _, args = get_dataset(args)
+    else:
+        train_dataset, _, args = get_dataset(args)
+    # this rank's block of whole trajectories (dataset.py:193-194 flattens (n_ics, n_steps, d) row-major)
+    n_ics, n_steps = train_dataset.n_ics, train_dataset.n_steps
+    lo, hi = rank * n_ics // world, (rank + 1) * n_ics // world
+    x_all = train_dataset.x[lo * n_steps:hi * n_steps].to(dev)
+    dx_all = train_dataset.dx[lo * n_steps:hi * n_steps].to(dev)
+    n_local = x_all.shape[0]
+    m = int(n_local * args['lbfgs_subsample'])
     seeds = list(range(args['seed'], args['seed'] + n_seeds))
+
+    truth = sindy_truth[args['task']]
+
+    def padded_truth(p, template):
+        if truth.shape[1] < p and not (template.include_sine or template.include_exp):
+            return np.concatenate([truth, np.zeros((truth.shape[0], p - truth.shape[1]))], axis=1)
+        return truth
+
+    if method == 'stlsq':
+        if args['eq_constraint']:
+            raise SystemExit('--method stlsq sweeps the unconstrained library (use --method lbfgs for EquivSINDy-c)')
+        sw = SeedSweepSTLSQ(x_all, dx_all, args['poly_order'], args['include_sine'], args['include_exp'], n_seeds=n_seeds,
+                            subsample=args['lbfgs_subsample'], seed0=args['seed'], group=group, engine=engine)
+        Xi, mask, passes = sw.solve(args['w_sindy_reg'], args['threshold'], max_iter=max(1, args['num_epochs']))
+        if rank == 0:
+            class _T:                                               # library flags for the truth-table padding
+                include_sine, include_exp = args['include_sine'], args['include_exp']
+            _write_results(args, seeds, Xi.numpy(), mask.numpy().astype(bool), padded_truth(mask.shape[-1], _T))
+            print(f'{n_seeds} seeds x {sw.n_points} points (over {world} rank(s)), STLSQ passes {int(passes.min())}-{int(passes.max())}')
+            return aggregate_results(args['save_dir'], min_seed=seeds[0], max_seed=seeds[-1] + 1)
+        return None
 
     # one template regressor fixes the library / constraint; per-seed draws follow the constructor's order
     if args['eq_constraint']:
@@ -50,7 +122,7 @@ def main(argv=None):
         L_list = gen.get_full_basis_list()
         rd = L_list[0].shape[-1] // args['n_comps']
         args['L_list'] = [L[:rd, :rd].detach().cpu() for L in L_list]
-    template = SINDyRegression(**args).to(dev)
+    template = SINDyRegression(**args, **({'engine': engine} if engine is not None else {})).to(dev)
     inits, xs, dxs = [], [], []
     for s in seeds:
         g = torch.Generator().manual_seed(s)
@@ -60,32 +132,23 @@ def main(argv=None):
             inits.append(torch.cat([beta, const]))
         else:
             inits.append(torch.randn(template.latent_dim * template.get_term_num(), generator=g))
-        rows = torch.randperm(len(train_dataset), generator=g)[:m].to(dev)
+        rows = torch.randperm(n_local, generator=g)[:m].to(dev)
         xs.append(x_all[rows])
         dxs.append(dx_all[rows])
     X, DX = torch.stack(xs).contiguous(), torch.stack(dxs).contiguous()
     clos = BatchedClosure(X, DX, template.poly_order, template.include_sine, template.include_exp,
                           Q=template.Q if template.constraint else None,
                           use_kron_product=getattr(template, 'use_kron_product', True),
-                          allow_constant=getattr(template, 'allow_constant', True))
+                          allow_constant=getattr(template, 'allow_constant', True), group=group,
+                          **({'engine': engine} if engine is not None else {}))
     sweep = SeedSweepLBFGS(clos, args['lr_sindy'], args['threshold'], args['st_freq'], w_sindy_x=args['w_sindy_x'],
                            sindy_reg_type=args['sindy_reg_type'], w_sindy_reg=args['w_sindy_reg'])
     out = sweep.fit(torch.stack(inits).to(dev), args['num_epochs'])
 
-    truth = sindy_truth[args['task']]
-    p = out['mask'].shape[-1]
-    if truth.shape[1] < p and not (template.include_sine or template.include_exp):
-        truth = np.concatenate([truth, np.zeros((truth.shape[0], p - truth.shape[1]))], axis=1)
-    eval_dir = f'eval_results/{args["save_dir"]}'
-    os.makedirs(eval_dir, exist_ok=True)
+    if rank != 0:
+        return None
     Xi, mask = out['Xi'].cpu().numpy(), out['mask'].cpu().numpy().astype(bool)
-    tmask = truth != 0
-    for k, s in enumerate(seeds):                                   # evaluation/eval_eq.py:7-34 per seed
-        coef = np.where(mask[k], Xi[k], 0.0)
-        cf = np.array([float(np.all(mask[k, i] == tmask[i])) for i in range(truth.shape[0])])
-        mse = np.array([np.mean((coef[i, tmask[i]] - truth[i, tmask[i]]) ** 2) for i in range(truth.shape[0])])
-        np.savez(f'{eval_dir}/seed{s}.npz', coefficients=coef, correct_form=cf, mse=mse, correct_form_all=np.all(cf),
-                 mse_all=np.mean(mse))
+    _write_results(args, seeds, Xi, mask, padded_truth(mask.shape[-1], template))
     print(f'{n_seeds} seeds, epochs used {int(out["epochs"].min())}-{int(out["epochs"].max())}, '
           f'finished {int(out["finished"].sum())}, NaN {int(out["nan"].sum())}')
     return aggregate_results(args['save_dir'], min_seed=seeds[0], max_seed=seeds[-1] + 1)
