@@ -82,7 +82,7 @@ inline bool vec_ok(const void* p, long n, int d, long S) {
     return ((uintptr_t)p % 16 == 0) && (S == 1 || (n * d) % 4 == 0);
 }
 
-constexpr int SGPR_XI_MAX = 48;     // largest D*P kept in SGPRs (the wave has ~100 of them; d = 2 up to order 5 fits)
+constexpr int SGPR_XI_MAX = 64;     // largest D*P kept in SGPRs (the wave has ~100 of them: d = 2 up to order 5, d = 3 order 3, d = 4 order 2)
 
 // Masked coefficients of problem s into registers (uniform across the block -> scalar loads).
 template <class Lib>
