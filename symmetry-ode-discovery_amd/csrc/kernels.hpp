@@ -464,6 +464,40 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
                 for (int k = 0; k < R; ++k)
                     if (c + k * nthreads < nchunks) chunk(rx[k], ry[k]);
             }
+        } else if constexpr ((VARIANT == 2 || VARIANT == 4) && D == 3) {
+            // 12-byte points: coalesced tile loads + wave-private LDS redistribution while the wave is whole
+            // (points.hpp); ragged waves fall back to the strided per-lane loads
+            __shared__ float4 slab3[BLOCK / WAVE][3 * WAVE];
+            const int lane = threadIdx.x & (WAVE - 1);
+            float4* slab = slab3[threadIdx.x / WAVE];
+            for (; c + nthreads < nchunks; c += 2 * nthreads) {
+                float4 ax[NV], ay[NV], bx[NV], by[NV];
+                if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {
+                    float4 tax[NV], tay[NV], tbx[NV], tby[NV];
+                    const long c0 = c - lane;
+                    load_tile3_raw<NT>(xs, c0, lane, tax);
+                    load_tile3_raw<NT>(ys, c0, lane, tay);
+                    load_tile3_raw<NT>(xs, c0 + nthreads, lane, tbx);
+                    load_tile3_raw<NT>(ys, c0 + nthreads, lane, tby);
+                    exchange_tile3(tax, ax, slab, lane);
+                    exchange_tile3(tay, ay, slab, lane);
+                    exchange_tile3(tbx, bx, slab, lane);
+                    exchange_tile3(tby, by, slab, lane);
+                } else {
+                    load_chunk_raw<D, NT>(xs, c, ax);
+                    load_chunk_raw<D, NT>(ys, c, ay);
+                    load_chunk_raw<D, NT>(xs, c + nthreads, bx);
+                    load_chunk_raw<D, NT>(ys, c + nthreads, by);
+                }
+                chunk(ax, ay);
+                chunk(bx, by);
+            }
+            if (c < nchunks) {
+                float4 ax[NV], ay[NV];
+                load_chunk_raw<D, NT>(xs, c, ax);
+                load_chunk_raw<D, NT>(ys, c, ay);
+                chunk(ax, ay);
+            }
         } else if constexpr (VARIANT == 2 || VARIANT == 4) {
             for (; c + nthreads < nchunks; c += 2 * nthreads) {
                 float4 ax[NV], ay[NV], bx[NV], by[NV];

@@ -50,6 +50,39 @@ __device__ __forceinline__ void load_chunk_raw(const float* __restrict__ a, long
     }
 }
 
+// D = 3: a point is 12 bytes, so chunk c of lane l (vectors 3c .. 3c+2) makes every 16-byte lane load 48-byte strided --
+// three requests each using a third of the lines they touch (measured 4.3 TB/s where d = 2 and d = 4 stream at 6.4-6.8).
+// A full wave instead fetches its 192-vector tile (256 points) coalesced -- lane l takes vectors l, 64+l, 128+l of the
+// tile -- and redistributes through a wave-private LDS slab: lane l reads back vectors 3l, 3l+1, 3l+2, its own chunk.
+// Preconditions (checked by the caller): all 64 lanes active, lane l holds chunk c0 + l.
+template <bool NT>
+__device__ __forceinline__ void load_tile3_raw(const float* __restrict__ a, long c0, int lane, float4 (&t)[3]) {
+    const float4* q = reinterpret_cast<const float4*>(a) + c0 * 3 + lane;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if constexpr (NT) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v u = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q + 64 * i));
+            t[i] = make_float4(u.x, u.y, u.z, u.w);
+        } else {
+            t[i] = q[64 * i];
+        }
+    }
+}
+
+// t (tile order) -> v (this lane's chunk) through slab[192]; the wave runs in lock step, so only the LDS counter
+// separates the writes from the reads (no workgroup barrier).
+__device__ __forceinline__ void exchange_tile3(const float4 (&t)[3], float4 (&v)[3], float4* slab, int lane) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) slab[64 * i + lane] = t[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = slab[3 * lane + i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                     // the next exchange reuses the slab
+}
+
 template <int D>
 __device__ __forceinline__ void unpack_chunk(const float4 (&v)[Chunk<D>::NV], float (&p)[Chunk<D>::PPT][D]) {
     constexpr int NV = Chunk<D>::NV;

@@ -129,6 +129,21 @@ def test_loss_grad_batched_problems(eng, S, n):
         assert_close_scaled(grad[s].cpu().numpy(), wg.numpy(), 2e-5)
 
 
+@pytest.mark.parametrize("S,n", [(4, 4096), (3, 10000), (2, 1028)])
+def test_loss_grad_batched_three_dimensional_states(eng, S, n):
+    """d = 3 (12-byte points): whole waves take the coalesced-tile + LDS-redistribution path, ragged ones the strided loads."""
+    torch.manual_seed(S + n)
+    d, order = 3, 3
+    p = O.term_count(d, order)
+    x, dx = torch.randn(S, n, d) * 0.7, torch.randn(S, n, d)
+    Xi, mask = torch.randn(S, d, p) * 0.5, (torch.rand(S, d, p) > 0.3).float()
+    loss, grad = eng.loss_grad(x.cuda(), dx.cuda(), Xi.cuda(), mask.cuda(), order)
+    for s in range(S):
+        wl, wg = O.mse_loss_and_grad(x[s].double(), dx[s].double(), Xi[s].double(), mask[s].double(), order)
+        assert np.isclose(loss[s].item(), wl.item(), rtol=2e-5)
+        assert_close_scaled(grad[s].cpu().numpy(), wg.numpy(), 2e-5)
+
+
 def test_loss_grad_is_deterministic(eng):
     torch.manual_seed(0)
     x, dx, Xi = torch.randn(125000, 2).cuda(), torch.randn(125000, 2).cuda(), torch.randn(2, 21).cuda()
