@@ -15,41 +15,6 @@ struct Chunk {
     static_assert(PPT * D == NV * 4, "chunk must be a whole number of 16-byte vectors");
 };
 
-template <int D>
-__device__ __forceinline__ void load_chunk(const float* __restrict__ a, long c, float (&p)[Chunk<D>::PPT][D]) {
-    constexpr int NV = Chunk<D>::NV;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v* q = reinterpret_cast<const f4v*>(a) + c * NV;
-    float f[NV * 4];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const f4v v = __builtin_nontemporal_load(q + i);          // streamed once
-        f[4 * i + 0] = v.x;
-        f[4 * i + 1] = v.y;
-        f[4 * i + 2] = v.z;
-        f[4 * i + 3] = v.w;
-    }
-#pragma unroll
-    for (int i = 0; i < NV * 4; ++i) p[i / D][i % D] = f[i];
-}
-
-// Raw 16-byte vectors of chunk c (optionally non-temporal: the stream is read exactly once).
-template <int D, bool NT>
-__device__ __forceinline__ void load_chunk_raw(const float* __restrict__ a, long c, float4 (&v)[Chunk<D>::NV]) {
-    constexpr int NV = Chunk<D>::NV;
-    const float4* q = reinterpret_cast<const float4*>(a) + c * NV;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        if constexpr (NT) {
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q + i));
-            v[i] = make_float4(t.x, t.y, t.z, t.w);
-        } else {
-            v[i] = q[i];
-        }
-    }
-}
-
 // D = 3: a point is 12 bytes, so chunk c of lane l (vectors 3c .. 3c+2) makes every 16-byte lane load 48-byte strided --
 // three requests each using a third of the lines they touch (measured 4.3 TB/s where d = 2 and d = 4 stream at 6.4-6.8).
 // A full wave instead fetches its 192-vector tile (256 points) coalesced -- lane l takes vectors l, 64+l, 128+l of the
@@ -83,6 +48,76 @@ __device__ __forceinline__ void exchange_tile3(const float4 (&t)[3], float4 (&v)
     __builtin_amdgcn_wave_barrier();                     // the next exchange reuses the slab
 }
 
+// Reverse direction for stores: v (this lane's chunk) -> t (tile order).
+__device__ __forceinline__ void exchange_tile3_out(const float4 (&v)[3], float4 (&t)[3], float4* slab, int lane) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) slab[3 * lane + i] = v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = slab[64 * i + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Wave-private LDS slab for the D = 3 tile exchange of a 256-thread workgroup (one per call site that needs it).
+#define SYMODE_TILE3_SLAB(name) __shared__ float4 name[4][192]
+
+template <int D>
+__device__ __forceinline__ void load_chunk(const float* __restrict__ a, long c, float (&p)[Chunk<D>::PPT][D]) {
+    constexpr int NV = Chunk<D>::NV;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    float f[NV * 4];
+    if constexpr (D == 3) {
+        // callers hand consecutive chunks to consecutive lanes (for_each_point): a whole wave takes the coalesced tile
+        if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {
+            SYMODE_TILE3_SLAB(slab);
+            const int lane = threadIdx.x & 63;
+            float4 t[3], v[3];
+            load_tile3_raw<true>(a, c - lane, lane, t);
+            exchange_tile3(t, v, slab[threadIdx.x >> 6], lane);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f[4 * i + 0] = v[i].x;
+                f[4 * i + 1] = v[i].y;
+                f[4 * i + 2] = v[i].z;
+                f[4 * i + 3] = v[i].w;
+            }
+#pragma unroll
+            for (int i = 0; i < NV * 4; ++i) p[i / D][i % D] = f[i];
+            return;
+        }
+    }
+    const f4v* q = reinterpret_cast<const f4v*>(a) + c * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f4v v = __builtin_nontemporal_load(q + i);          // streamed once
+        f[4 * i + 0] = v.x;
+        f[4 * i + 1] = v.y;
+        f[4 * i + 2] = v.z;
+        f[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NV * 4; ++i) p[i / D][i % D] = f[i];
+}
+
+// Raw 16-byte vectors of chunk c (optionally non-temporal: the stream is read exactly once).
+template <int D, bool NT>
+__device__ __forceinline__ void load_chunk_raw(const float* __restrict__ a, long c, float4 (&v)[Chunk<D>::NV]) {
+    constexpr int NV = Chunk<D>::NV;
+    const float4* q = reinterpret_cast<const float4*>(a) + c * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if constexpr (NT) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q + i));
+            v[i] = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            v[i] = q[i];
+        }
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void unpack_chunk(const float4 (&v)[Chunk<D>::NV], float (&p)[Chunk<D>::PPT][D]) {
     constexpr int NV = Chunk<D>::NV;
@@ -105,6 +140,20 @@ __device__ __forceinline__ void store_chunk(float* __restrict__ a, long c, const
     float f[NV * 4];
 #pragma unroll
     for (int i = 0; i < NV * 4; ++i) f[i] = p[i / D][i % D];
+    if constexpr (D == 3) {
+        if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {           // whole wave: coalesced tile stores (see load_chunk)
+            SYMODE_TILE3_SLAB(slab);
+            const int lane = threadIdx.x & 63;
+            float4 v[3], t[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+            exchange_tile3_out(v, t, slab[threadIdx.x >> 6], lane);
+            float4* tile = reinterpret_cast<float4*>(a) + (c - lane) * 3 + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tile[64 * i] = t[i];
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) q[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
 }

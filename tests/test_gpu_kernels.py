@@ -183,6 +183,24 @@ def test_odeint_golden(eng, golden, tag):
     assert torch.equal(eng.odeint(x, Xi, mask, order, fl, 0, dt), x)
 
 
+@pytest.mark.parametrize("n", [1, 255, 256, 1027, 4096, 125000])
+@pytest.mark.parametrize("d,order,fl", [(3, 3, 0), (3, 2, 3), (1, 4, 0), (2, 3, 0), (4, 2, 0)])
+def test_forward_and_odeint_chunked_streams_vs_oracle(eng, n, d, order, fl):
+    """Streaming map kernels at ragged and full sizes for every chunk layout (d = 1: 4 points per 16 bytes, d = 2: 2, d = 3:
+    coalesced 192-vector tiles redistributed through LDS for whole waves / strided loads for ragged ones, d = 4: 1)."""
+    torch.manual_seed(n + d)
+    p = O.term_count(d, order, bool(fl & 1), bool(fl & 2))
+    x, Xi = (torch.randn(n, d) * 0.3).clamp(-0.6, 0.6), torch.randn(d, p) * 0.2
+    mask = (torch.rand(d, p) > 0.3).float()
+    want = O.forward(x, Xi, mask, order, bool(fl & 1), bool(fl & 2))
+    got = eng.forward(x.cuda(), Xi.cuda(), mask.cuda(), order, fl)
+    assert_close_scaled(got.cpu().numpy(), want.numpy(), 2e-6, f"forward n={n} d={d}")
+    f = lambda a: O.forward(a, Xi, mask, order, bool(fl & 1), bool(fl & 2))  # noqa: E731
+    want = O.odeint(f, x, 5 * 0.02 + 0.01, 0.02, "rk4")
+    got = eng.odeint(x.cuda(), Xi.cuda(), mask.cuda(), order, fl, 5, 0.02, "rk4")
+    assert np.allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("d,order,fl,method", [(2, 3, 0, "rk4"), (2, 2, 2, "rk4"), (2, 5, 0, "euler"), (3, 2, 1, "rk4"), (1, 3, 0, "euler"), (4, 2, 0, "rk4")])
 def test_odeint_full_trajectory_vs_oracle_steps(eng, d, order, fl, method):
     """symode_odeint_traj: the state after EVERY step equals the oracle's chained fp32 steps (odeint(..., full_traj=True));
