@@ -81,3 +81,22 @@ def test_engine_refuses_cpu_tensors():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(symode_amd.SymodeError):
         engine.load_library(str(tmp_path / "nope.so"))
+
+
+def test_header_is_plain_c_and_the_c_example_compiles():
+    """The boundary must be bindable from C / any FFI: include/symode.h parses as C99, examples/capi_demo.c type-checks
+    against it (gcc, no ROCm needed), and with the HIP runtime headers it links against the built library as C."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo, inc = os.path.join(root, "examples", "capi_demo.c"), os.path.join(root, "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", f"-I{inc}", "-DSYMODE_DEMO_NO_HIP", demo],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")) and os.path.exists(engine.LIB_PATH):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "symode_capi_demo")
+        libdir = os.path.dirname(engine.LIB_PATH)
+        r = subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", f"-I{inc}", demo, f"-L{libdir}",
+                            "-lsymode_hip", f"-L{rocm}/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}/lib",
+                            "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]

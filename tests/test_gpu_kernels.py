@@ -6,6 +6,9 @@ Tolerances (north_star: coefficients within rtol 1e-5 fp32, masks bit-exact):
   * reductions (loss, gradient): rtol 1e-5 relative to the gradient's scale;
   * fp64 Gram: rtol 1e-12 against an fp64 host product of the same fp32 library.
 """
+import os
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -345,3 +348,22 @@ def test_roofline_shape_2_27_points_single_problem(eng):
     assert np.isclose(loss.item(), want_loss.item(), rtol=2e-5)
     assert_close_scaled(grad.cpu().numpy(), want_grad.cpu().numpy(), 2e-5)
     assert abs(G[0, 0].item() - N) < 0.5                      # the constant column counts the points exactly
+
+
+def test_plain_c_caller_of_the_abi_runs(tmp_path):
+    """examples/capi_demo.c -- a C99 program with no Python and no torch -- drives symode_loss_grad through the C ABI."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from symode_amd import engine
+    libdir, rocm = os.path.dirname(engine.LIB_PATH), os.environ.get("ROCM_PATH", "/opt/rocm")
+    exe = str(tmp_path / "capi_demo")
+    subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", f"-I{root}/include", f"{root}/examples/capi_demo.c",
+                    f"-L{libdir}", "-lsymode_hip", f"-L{rocm}/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}/lib",
+                    "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    loss, grad = [float(v) for v in re.findall(r"[-+]?\d\.\d+e[-+]\d+", out)]
+    i = np.arange(125000)
+    b = (-1.0 + 2.0 * (i % 613).astype(np.float32) / np.float32(613.0)).astype(np.float64)
+    assert "10 terms" in out
+    assert np.isclose(loss, np.mean((0.05 * b) ** 2) / 2, rtol=1e-4)              # only dx1 is off: residual 0.05 * x1, mean over n*d
+    assert np.isclose(grad, 2 * np.mean(0.05 * b * b) / 2, rtol=1e-4)             # d loss / d Xi[1][x1 column]
