@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 "$R/bench.py" --steps 20 --warmup 3 --profile > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 "$R/bench.py" --steps 5 --warmup 1 --profile > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 "$R/bench.py" --steps 5 --warmup 1 --profile > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ops -- python3 "$R/tools/ops_table.py" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ops -- python3 "$R/tests/perf/ops_table.py" > /dev/null 2>&1
 cd "$R"
 python tools/rocprof_summary.py /tmp/prof_bench > gpurun_out/r01_bench_kernel_stats.txt
 python tools/rocprof_summary.py /tmp/prof_ops > gpurun_out/r01_ops_kernel_stats.txt
