@@ -4,7 +4,7 @@ rotating-spiral field, `train_lassi` for a few epochs on the GPU; reports second
 time goes (autoencoder + GAN on stock PyTorch-ROCm vs the latent least-squares solve on the HIP engine), and the
 same solve on the CPU oracle for scale.
 
-    python tools/e2e_lassi.py --epochs 3
+    python tests/perf/e2e_lassi.py --epochs 3
 """
 import argparse
 import contextlib

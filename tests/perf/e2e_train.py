@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end L-BFGS discovery run (train_SIGED_lbfgs) on the GPU next to the CPU oracle's restatement.
 
-    python tools/e2e_train.py [--order 3] [--n_ics 50] [--steps 2500]
+    python tests/perf/e2e_train.py [--order 3] [--n_ics 50] [--steps 2500]
 """
 import argparse
 import contextlib

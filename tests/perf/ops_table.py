@@ -2,7 +2,7 @@
 """Per-operation GPU (HIP path) vs CPU (oracle = port of the reference op sequence) timings, following the
 protocol of BASELINE.md section 3: 3 warm-ups, median of >= 20 repetitions, host threads stated, same inputs.
 
-    python tools/ops_table.py > profiles/r01_ops_table.md
+    python tests/perf/ops_table.py > profiles/r01_ops_table.md
 """
 import os
 import statistics

@@ -3,7 +3,7 @@
 autoencoder MLP 512 x 5 with batch norm, n_comps 2, generator (2,1,2), K = 10 Euler steps) -- GPU path
 (HIP kernels for everything that touches the library, stock PyTorch-ROCm for the MLP) vs the CPU oracle.
 
-    python tools/symreg_bench.py [--n 20000] [--hidden 512] [--layers 5]
+    python tests/perf/symreg_bench.py [--n 20000] [--hidden 512] [--layers 5]
 """
 import argparse
 import copy
