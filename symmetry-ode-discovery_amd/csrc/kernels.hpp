@@ -1221,6 +1221,72 @@ inline int loss_grad_variant() {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------
+// K1 for large libraries (D * P > SGPR_XI_MAX: d = 3 order 4, d = 4 order 3, sine/exp variants): one ROW per wave.
+// The thread-per-point form needs 1 + D*P accumulators and D*P coefficients in VGPRs per lane there (390-430
+// registers: one wave per SIMD, 1.5-1.8 TB/s).  Here a workgroup is D waves over the same 64 points per step; wave j
+// owns row j of Xi -- P coefficients in SGPRs, P + 1 accumulators -- evaluates Theta itself (34 redundant multiplies
+// per wave at p = 35 against 70 fused multiply-adds of its own) and reads only component j of dx.  ~100 VGPRs, 4-5
+// waves per SIMD; the D waves hit the same lines, so HBM sees every point once.
+// Partials land in the same ws[(s*G + b)*NACC + k] layout as the thread-per-point form, finalize_kernel is shared.
+// ---------------------------------------------------------------------------------------
+template <class Lib>
+__global__ __launch_bounds__(Lib::D* WAVE) void loss_grad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dx,
+                                                                      long N, const float* __restrict__ xi,
+                                                                      const float* __restrict__ mask, double* __restrict__ ws) {
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    __shared__ double loss_part[D];
+    const long s = blockIdx.y;
+    const int row = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const float* xs = x + s * N * D;
+    const float* ys = dx + s * N * D;
+    float w[P];                                                     // row `row` of Xi * mask, wave-uniform -> SGPRs
+    {
+        const float* a = xi + (s * D + row) * P;
+#pragma unroll
+        for (int k = 0; k < P; ++k) w[k] = a[k];
+        if (mask != nullptr) {
+            const float* m = mask + (s * D + row) * P;
+#pragma unroll
+            for (int k = 0; k < P; ++k) w[k] *= m[k];
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[k])));
+    }
+    float acc[P], sq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < P; ++k) acc[k] = 0.0f;
+    for (long n = (long)blockIdx.x * WAVE + lane; n < N; n += (long)gridDim.x * WAVE) {
+        float xp[D], th[P];
+        load_point<D>(xs, n, xp);
+        const float y = ys[n * D + row];
+        Lib::eval(xp, th);
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < P; ++k) r = fmaf(w[k], th[k], r);
+        r -= y;
+        sq = fmaf(r, r, sq);
+#pragma unroll
+        for (int k = 0; k < P; ++k) acc[k] = fmaf(r, th[k], acc[k]);
+    }
+    // wave-level butterfly (deterministic), lane 0 of every wave leaves its row's fp64 partials
+    double* dst = ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * NACC;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const float t = wave_sum(acc[k]);
+        if (lane == 0) dst[1 + row * P + k] = (double)t;
+    }
+    const float tsq = wave_sum(sq);
+    if (lane == 0) loss_part[row] = (double)tsq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) t += loss_part[j];
+        dst[0] = t;
+    }
+}
+
 template <class Lib>
 hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, const float* xi, const float* mask,
                             float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
@@ -1243,6 +1309,18 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // in SGPRs (every task the reference ships).  Larger libraries (d = 3, 4 at orders 3-4: 390-430 VGPRs already)
     // would spill, so they keep the two-chunk form and the experimental variants are not even instantiated for them.
     constexpr bool TUNED = (Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX);
+    constexpr bool ROWS = (Lib::D >= 2) && (Lib::D * Lib::P > SGPR_XI_MAX);
+    static const int rows_env = getenv("SYMODE_ROW_SPLIT") ? atoi(getenv("SYMODE_ROW_SPLIT")) : 1;
+    if constexpr (ROWS) {
+        if (rows_env != 0) {
+            // a workgroup covers 64 points per step: give it as many steps as the thread-per-point form has
+            loss_grad_rows_kernel<Lib><<<grid, dim3(Lib::D * WAVE), 0, st>>>(x, dx, n, xi, mask, ws);
+            SYMODE_LAUNCH_CHECK();
+            finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv_count, 2.0f * inv_count, loss, grad);
+            SYMODE_LAUNCH_CHECK();
+            return hipSuccess;
+        }
+    }
     int variant = loss_grad_variant();
     if (variant < 0) variant = TUNED ? 7 : 4;
     if (!TUNED && variant != 0) variant = 4;

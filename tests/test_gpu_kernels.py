@@ -91,7 +91,7 @@ def test_forward_loss_grad_golden(eng, golden, tag):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 65, 255, 1023, 4097, 125000])
-@pytest.mark.parametrize("d,order,fl", [(2, 3, 0), (2, 5, 0), (1, 3, 1), (3, 2, 2), (4, 2, 0)])
+@pytest.mark.parametrize("d,order,fl", [(2, 3, 0), (2, 5, 0), (1, 3, 1), (3, 2, 2), (4, 2, 0), (4, 3, 0), (3, 4, 1), (3, 3, 3), (4, 2, 3)])
 def test_loss_grad_ragged_sizes_vs_oracle(eng, n, d, order, fl):
     torch.manual_seed(n + 7 * d + order)
     x, dx = torch.randn(n, d) * 0.8, torch.randn(n, d)
@@ -143,6 +143,23 @@ def test_loss_grad_batched_three_dimensional_states(eng, S, n):
     loss, grad = eng.loss_grad(x.cuda(), dx.cuda(), Xi.cuda(), mask.cuda(), order)
     for s in range(S):
         wl, wg = O.mse_loss_and_grad(x[s].double(), dx[s].double(), Xi[s].double(), mask[s].double(), order)
+        assert np.isclose(loss[s].item(), wl.item(), rtol=2e-5)
+        assert_close_scaled(grad[s].cpu().numpy(), wg.numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("d,order,fl,S,n", [(4, 3, 0, 3, 5000), (3, 4, 0, 4, 4099), (4, 3, 2, 2, 777)])
+def test_loss_grad_large_libraries_row_per_wave(eng, d, order, fl, S, n):
+    """d*p > 64: the row-per-wave kernel (a workgroup = d waves over the same points, wave j owns row j of Xi), batched."""
+    torch.manual_seed(S + n)
+    p = O.term_count(d, order, bool(fl & 1), bool(fl & 2))
+    assert d * p > 64
+    x, dx = torch.randn(S, n, d) * 0.6, torch.randn(S, n, d)
+    Xi, mask = torch.randn(S, d, p) * 0.3, (torch.rand(S, d, p) > 0.3).float()
+    loss, grad = eng.loss_grad(x.cuda(), dx.cuda(), Xi.cuda(), mask.cuda(), order, fl)
+    again = eng.loss_grad(x.cuda(), dx.cuda(), Xi.cuda(), mask.cuda(), order, fl)
+    assert torch.equal(loss, again[0]) and torch.equal(grad, again[1])               # deterministic
+    for s in range(S):
+        wl, wg = O.mse_loss_and_grad(x[s].double(), dx[s].double(), Xi[s].double(), mask[s].double(), order, bool(fl & 1), bool(fl & 2))
         assert np.isclose(loss[s].item(), wl.item(), rtol=2e-5)
         assert_close_scaled(grad[s].cpu().numpy(), wg.numpy(), 2e-5)
 
