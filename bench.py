@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--n_ics", type=int, default=50)
     ap.add_argument("--n_steps", type=int, default=2500)
     ap.add_argument("--poly_order", type=int, default=5)
-    ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernel (default 1: one collective)")
+    ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernel (default: 1 on one GPU, 2 when the [loss|grad] buffer is all-reduced)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--shard", choices=["points", "seeds"], default="points",
@@ -134,7 +134,7 @@ def main():
     so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
     Q, use_kron = constraint_Q([so2], d, order)
     Q = Q.to(dev)
-    n_chunks = a.chunks or 1
+    n_chunks = a.chunks or (2 if (use_dist and a.shard == "points") else 1)
     clos = BatchedClosure(x, dx, order, Q=Q, use_kron_product=use_kron, allow_constant=True,
                           group=dist.group.WORLD if (use_dist and a.shard == "points") else None, n_chunks=n_chunks, engine=eng)
     g = torch.Generator(device=dev)
