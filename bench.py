@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--problems", type=int, default=2048, help="(trajectory, seed) problems per GPU")
+    ap.add_argument("--problems", type=int, default=8192, help="(trajectory, seed) problems per GPU")
     ap.add_argument("--n_ics", type=int, default=50)
     ap.add_argument("--n_steps", type=int, default=2500)
     ap.add_argument("--poly_order", type=int, default=5)

@@ -13,6 +13,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ops -- python3
 cd "$R"
 python tools/rocprof_summary.py /tmp/prof_bench > gpurun_out/r01_bench_kernel_stats.txt
 python tools/rocprof_summary.py /tmp/prof_ops > gpurun_out/r01_ops_kernel_stats.txt
-python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write loss_grad_kernel 2097152 256000000 > gpurun_out/pmc_traffic.json
+python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write loss_grad_kernel 4194304 1024000000 > gpurun_out/pmc_traffic.json
 head -4 gpurun_out/r01_bench_kernel_stats.txt
 python -c 'import json; r=json.load(open("gpurun_out/r01_bench_n1.json")); print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["cpu_baseline"]["value"])'
