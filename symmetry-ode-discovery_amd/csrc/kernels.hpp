@@ -1256,10 +1256,26 @@ __global__ __launch_bounds__(Lib::D* WAVE) void loss_grad_rows_kernel(const floa
     float acc[P], sq = 0.0f;
 #pragma unroll
     for (int k = 0; k < P; ++k) acc[k] = 0.0f;
-    for (long n = (long)blockIdx.x * WAVE + lane; n < N; n += (long)gridDim.x * WAVE) {
+    // one point per lane per step, the next step's operands requested before this step's ~3p VALU ops (clamped index:
+    // the last prefetch re-reads an in-bounds point)
+    const long stride = (long)gridDim.x * WAVE;
+    long n = (long)blockIdx.x * WAVE + lane;
+    float xn[D], yn = 0.0f;
+    {
+        const long q = n < N ? n : N - 1;
+        load_point<D>(xs, q, xn);
+        yn = ys[q * D + row];
+    }
+    for (; n < N; n += stride) {
         float xp[D], th[P];
-        load_point<D>(xs, n, xp);
-        const float y = ys[n * D + row];
+#pragma unroll
+        for (int i = 0; i < D; ++i) xp[i] = xn[i];
+        const float y = yn;
+        {
+            const long q = n + stride < N ? n + stride : N - 1;
+            load_point<D>(xs, q, xn);
+            yn = ys[q * D + row];
+        }
         Lib::eval(xp, th);
         float r = 0.0f;
 #pragma unroll
