@@ -33,6 +33,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
 #pragma unroll
         for (int i = 0; i < NA; ++i) s += acc[i];
         out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;
+    } else if constexpr (MODE == 3) {   // the forward pattern: s = fma(w (SGPR), th[i] (VGPR), s (VGPR)) on 4 independent chains
+        float th[NA], sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NA; ++i) th[i] = threadIdx.x * 3e-3f - i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) sacc[i & 3] = __builtin_fmaf(a + (float)i, th[i], sacc[i & 3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) th[i] += sacc[i] * 1e-9f;
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = sacc[0] + sacc[1] + sacc[2] + sacc[3];
     } else {   // MODE 2: v_fmac with an SGPR operand and distinct VGPR sources (the loss/gradient pattern)
         float acc[NA], th[NA];
 #pragma unroll
@@ -83,5 +94,6 @@ int main() {
     run<0>("v_fma_f32", cus, out);
     run<1>("v_pk_fma_f32", cus, out);
     run<2>("v_fmac(r,th)", cus, out);
+    run<3>("v_fmac(s,th)", cus, out);
     return 0;
 }
