@@ -82,6 +82,9 @@ inline bool vec_ok(const void* p, long n, int d, long S) {
     return ((uintptr_t)p % 16 == 0) && (S == 1 || (n * d) % 4 == 0);
 }
 
+#ifndef SYMODE_ROWS_XI_SGPR
+#define SYMODE_ROWS_XI_SGPR 1       // loss_grad_rows_kernel: its row of Xi in SGPRs (1) or VGPRs (0); measured 555 vs 587 us at p = 35
+#endif
 constexpr int VGPR_XI_MAX = 48;     // up to here the masked coefficients simply stay in VGPRs (see load_xi)
 constexpr int SGPR_XI_MAX = 64;     // largest D*P kept in SGPRs (the wave has ~100 of them: d = 2 up to order 5, d = 3 order 3, d = 4 order 2)
 
@@ -1253,8 +1256,10 @@ __global__ __launch_bounds__(Lib::D* WAVE) void loss_grad_rows_kernel(const floa
 #pragma unroll
             for (int k = 0; k < P; ++k) w[k] *= m[k];
         }
+#if SYMODE_ROWS_XI_SGPR
 #pragma unroll
         for (int k = 0; k < P; ++k) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[k])));
+#endif
     }
     float acc[P], sq = 0.0f;
 #pragma unroll
