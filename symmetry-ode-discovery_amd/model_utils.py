@@ -12,6 +12,7 @@
 """
 from __future__ import annotations
 
+import weakref
 from functools import partial
 
 import torch
@@ -281,12 +282,15 @@ def symmreg_r(x, autoencoder, generator, h, normalize='global', z_mean=None, req
     generator.eval()
     frozen = not any(p.requires_grad for p in list(autoencoder.parameters()) + list(generator.parameters()))
     if isinstance(h, SINDyRegression) and normalize == 'global' and frozen and x.is_cuda:
-        key = (x.data_ptr(), x._version, tuple(x.shape), id(autoencoder), id(generator), float(scale))
-        if key not in _R_CACHE:
-            _R_CACHE.clear()
+        # identity of the LIVE tensor object + its version, not its address: the allocator hands the address of a freed
+        # batch to the next one (every epoch draws a new subsample, main.py:36-38), a weak reference to it dies instead
+        key = (x._version, tuple(x.shape), id(autoencoder), id(generator), float(scale))
+        hit = _R_CACHE.get('entry')
+        if hit is None or hit[0]() is not x or hit[1] != key:
             gx, jgx = precompute_symmreg_r(x, autoencoder, generator, z_mean=z_mean, scale=scale)
-            _R_CACHE[key] = (torch.stack(gx).contiguous(), torch.stack(jgx).contiguous())
-        gx, jgx = _R_CACHE[key]
+            hit = (weakref.ref(x), key, torch.stack(gx).contiguous(), torch.stack(jgx).contiguous())
+            _R_CACHE['entry'] = hit
+        gx, jgx = hit[2], hit[3]
         with torch.set_grad_enabled(require_grad):
             return _ReversedFused.apply(h.get_Xi(), h.mask, x, gx, jgx, h)
     jvp_fn = _jvp_fn(require_grad)

@@ -301,3 +301,30 @@ def test_fused_euler_flow_matches_stepwise_tangent_flow_and_its_gradients(S):
             assert torch.allclose(a, b, rtol=2e-4, atol=2e-5 * max(b.abs().max().item(), 1e-6)), (d, order, nm)
         with torch.no_grad():
             assert torch.allclose(flow(x), out[0][0].to(DEV), rtol=1e-5, atol=1e-6)     # odeint kernel == fused flow
+
+
+def test_caches_follow_the_tensor_object_not_its_address(S, golden):
+    """Every epoch draws a new subsample (main.py:36-38) and the allocator hands the freed batch's address to the next one:
+    the (g(x), J_g(x)) cache of the reversed regulariser and the Gram cache must key on the live tensor, not on data_ptr."""
+    g = golden("f6_symreg")
+    ae = load_fixture_autoencoder(g, "tanh_learn", "Tanh", DEV)
+    gen = load_fixture_generator(g, "tanh_learn", "(2,1,2)", DEV)
+    for p in list(ae.parameters()) + list(gen.parameters()):
+        p.requires_grad = False
+    r = S.SINDyRegression(2, 2, False, False, threshold=0.05, device=DEV)
+    torch.manual_seed(0)
+    x1 = (torch.randn(4096, 2) * 0.5).to(DEV)
+    l1 = S.model_utils.symmreg_r(x1, ae, gen, h=r).item()
+    y1 = torch.randn(4096, 2).to(DEV)
+    G1 = r.aug_gram(x1, y1).copy()
+    addr = x1.data_ptr()
+    del x1
+    x2 = (torch.randn(4096, 2) * 0.5 + 0.3).to(DEV)                # same size, allocated right after the free
+    if x2.data_ptr() != addr:
+        pytest.skip("the allocator did not recycle the address in this process")
+    l2 = S.model_utils.symmreg_r(x2, ae, gen, h=r).item()
+    S.model_utils._R_CACHE.clear()
+    fresh = S.model_utils.symmreg_r(x2, ae, gen, h=r).item()
+    assert l2 == fresh and l2 != l1
+    G2 = r.aug_gram(x2, y1)
+    assert not np.allclose(G1, G2) and np.allclose(G2, S.get_engine().aug_gram(x2, y1, 2, 0).cpu().numpy())
