@@ -130,6 +130,66 @@ def _jvp_fn(require_grad):
     return partial(jvp, create_graph=True, strict=True) if require_grad else jvp
 
 
+def mlp_jvp(module, h, t):
+    """(module(h), J_module(h) t) by forward-mode propagation through the stock layers of the autoencoder: Linear
+    (parametrised weights included), eval-mode BatchNorm1d, Reshape / Identity, nested Sequential and the elementwise
+    activations.  One pass of twice the GEMMs instead of the double-backward trick of ``torch.autograd.functional.jvp``
+    (forward + a backward w.r.t. a dummy cotangent + its differentiation); ordinary autograd differentiates the result.
+    Returns None when a layer is not covered (the caller falls back to the functional jvp)."""
+    import torch.nn as nn
+    from .autoencoder import Reshape
+    if isinstance(module, nn.Sequential):
+        for layer in module:
+            out = mlp_jvp(layer, h, t)
+            if out is None:
+                return None
+            h, t = out
+        return h, t
+    if isinstance(module, nn.Identity):
+        return h, t
+    if isinstance(module, Reshape):
+        return h.reshape(module.shape), t.reshape(module.shape)
+    if isinstance(module, nn.Linear):
+        W = module.weight
+        return torch.nn.functional.linear(h, W, module.bias), torch.nn.functional.linear(t, W)
+    if isinstance(module, nn.BatchNorm1d):
+        if module.training or module.running_var is None:
+            return None
+        scale = torch.rsqrt(module.running_var + module.eps)
+        if module.weight is not None:
+            scale = scale * module.weight
+        shift = -module.running_mean * scale + (module.bias if module.bias is not None else 0.0)
+        return h * scale + shift, t * scale
+    if isinstance(module, nn.ReLU):
+        return torch.relu(h), t * (h > 0).to(t.dtype)
+    if isinstance(module, nn.LeakyReLU):
+        slope = torch.where(h > 0, torch.ones_like(h), torch.full_like(h, module.negative_slope))
+        return torch.nn.functional.leaky_relu(h, module.negative_slope), t * slope
+    if isinstance(module, nn.Tanh):
+        y = torch.tanh(h)
+        return y, t * (1.0 - y * y)
+    if isinstance(module, nn.Sigmoid):
+        y = torch.sigmoid(h)
+        return y, t * (y * (1.0 - y))
+    if isinstance(module, nn.SiLU):
+        sg = torch.sigmoid(h)
+        return h * sg, t * (sg * (1.0 + h * (1.0 - sg)))
+    if isinstance(module, nn.ELU):
+        e = module.alpha * torch.exp(h)
+        return torch.where(h > 0, h, e - module.alpha), t * torch.where(h > 0, torch.ones_like(h), e)
+    if isinstance(module, nn.Softplus) and module.beta == 1:
+        return torch.nn.functional.softplus(h, threshold=module.threshold), t * torch.sigmoid(h)
+    return None
+
+
+def _module_jvp(module, h, t, require_grad):
+    """J_module(h) t: analytic forward mode where the layers allow it, the reference's functional jvp otherwise."""
+    out = mlp_jvp(module, h, t)
+    if out is not None:
+        return out[1]
+    return _jvp_fn(require_grad)(module, h, v=t)[1]
+
+
 # --------------------------------------------------------------------------------------------
 # S2: infinitesimal                                                   ref: model_utils.py:8-67
 # --------------------------------------------------------------------------------------------
@@ -159,7 +219,7 @@ def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global
         z_shape = z.shape
         for v in generator.get_full_basis_list():
             v_z = torch.einsum('jk,...k->...j', v, z.reshape(z_shape[0], -1)).reshape(z_shape)
-            v_x_fx = jvp_fn(autoencoder.decoder, z, v=v_z)[1]                    # stock PyTorch MLP jvp
+            v_x_fx = _module_jvp(autoencoder.decoder, z, v_z, require_grad)      # stock PyTorch MLP, forward-mode tangent
             v_x, v_fx = v_x_fx[:, 0], v_x_fx[:, 1]
             if f is not None:
                 if isinstance(f, _EulerFlow):
@@ -231,6 +291,26 @@ def _group_transform(x, autoencoder, g, normalize='global', z_mean=None):
     return autoencoder.decode(g_z)[:, 0]
 
 
+def _group_transform_jvp(x, v, autoencoder, g, normalize='global', z_mean=None):
+    """(g(x), J_g(x) v) by forward mode through encoder -> group element -> decoder; None if a layer is not covered."""
+    xx, vv = torch.stack([x, x], dim=1), torch.stack([v, v], dim=1)
+    enc = mlp_jvp(autoencoder.encoder, xx, vv)
+    if enc is None:
+        return None
+    z, tz = enc
+    if normalize == 'in_batch':
+        zm, tzm = z.mean(dim=0, keepdim=True), tz.mean(dim=0, keepdim=True)
+    else:
+        zm, tzm = _z_mean(autoencoder, z_mean), 0.0
+    shape = z.shape
+    act = lambda a: torch.einsum('jk,...k->...j', g, a.reshape(shape[0], -1)).reshape(shape)  # noqa: E731
+    g_z, t_gz = act(z - zm) + zm, act(tz - tzm) + tzm
+    dec = mlp_jvp(autoencoder.decoder, g_z, t_gz)
+    if dec is None:
+        return None
+    return dec[0][:, 0], dec[1][:, 0]
+
+
 def precompute_symmreg_r(x, autoencoder, generator, z_mean=None, scale=0.01):
     '''
     g(x) and J_g(x) for every deterministic group element -- they do not depend on the ODE, so
@@ -250,7 +330,8 @@ def precompute_symmreg_r(x, autoencoder, generator, z_mean=None, scale=0.01):
             for j in range(d):
                 e = torch.zeros_like(x)
                 e[:, j] = 1.0
-                cols.append(jvp(tr, x, v=e)[1])
+                fast = _group_transform_jvp(x, e, autoencoder, g, normalize='global', z_mean=z_mean)
+                cols.append(fast[1] if fast is not None else jvp(tr, x, v=e)[1])
             Jgx_list.append(torch.stack(cols, dim=-1))
     return gx_list, Jgx_list
 

@@ -120,3 +120,44 @@ def test_unknown_tasks_and_autoencoders_raise_like_the_reference():
         get_dataset({"task": "nope", "noise": 0.0, "smoothing": None})
     with pytest.raises(NotImplementedError):
         AutoEncoder(ae_arch="stick_cnn")
+
+
+@pytest.mark.parametrize("act", ["ReLU", "Tanh", "Sigmoid", "SiLU", "ELU", "LeakyReLU", "Softplus"])
+@pytest.mark.parametrize("bn,ortho", [(False, False), (True, True)])
+def test_forward_mode_mlp_jvp_equals_functional_jvp(act, bn, ortho):
+    """model_utils.mlp_jvp (analytic forward mode through the autoencoder's layers) against torch.autograd.functional.jvp
+    -- values, tangents, and their gradients -- in fp64; the group transform g(x) = dec(g (enc(x) - mu) + mu) likewise."""
+    from functools import partial
+    from torch.autograd.functional import jvp
+    from symode_amd.autoencoder import AutoEncoder
+    from symode_amd.model_utils import _group_transform, _group_transform_jvp, mlp_jvp
+    torch.manual_seed(0)
+    ae = AutoEncoder(ae_arch="mlp", input_dim=3, hidden_dim=16, latent_dim=2, n_layers=3, n_comps=2, activation=act,
+                     activation_args=[], batch_norm=bn, ortho_ae=ortho).double()
+    for m in ae.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.7, 1.3)
+            m.bias.data.normal_(0, 0.2)
+    ae.eval()
+    z = torch.randn(7, 2, 2, dtype=torch.float64, requires_grad=True)
+    v = torch.randn(7, 2, 2, dtype=torch.float64, requires_grad=True)
+    y, ty = mlp_jvp(ae.decoder, z, v)
+    yr, tyr = jvp(ae.decoder, z, v=v, create_graph=True)
+    assert torch.allclose(y, yr) and torch.allclose(ty, tyr, atol=1e-12)
+    ga = torch.autograd.grad((ty ** 2).sum() + (y ** 3).sum(), [z, v], allow_unused=True)
+    gb = torch.autograd.grad((tyr ** 2).sum() + (yr ** 3).sum(), [z, v], allow_unused=True)
+    for a, b in zip(ga, gb):
+        a = torch.zeros_like(z) if a is None else a
+        b = torch.zeros_like(z) if b is None else b
+        assert torch.allclose(a, b, atol=1e-10)
+    x, e = torch.randn(9, 3, dtype=torch.float64), torch.randn(9, 3, dtype=torch.float64)
+    g = torch.matrix_exp(torch.randn(4, 4, dtype=torch.float64) * 0.1)
+    zmean = torch.randn(2, dtype=torch.float64) * 0.1
+    for nrm in ("global", "in_batch"):
+        tr = partial(_group_transform, autoencoder=ae, g=g, normalize=nrm, z_mean=zmean)
+        a, b = _group_transform_jvp(x, e, ae, g, nrm, zmean), jvp(tr, x, v=e)
+        assert torch.allclose(a[0], b[0], atol=1e-12) and torch.allclose(a[1], b[1], atol=1e-10)
+    ae.train()                                                  # train-mode batch norm couples the samples: not covered
+    assert (mlp_jvp(ae.encoder, torch.randn(5, 2, 3, dtype=torch.float64), torch.randn(5, 2, 3, dtype=torch.float64)) is None) == bn
