@@ -191,10 +191,66 @@ def _module_jvp(module, h, t, require_grad):
 
 
 # --------------------------------------------------------------------------------------------
+# The Xi-independent half of S2 / S3.  x_fx = [x | f(x)] goes through the autoencoder component by component (Linear
+# layers act on the last axis, eval-mode BatchNorm is a per-feature affine map), and the generators / group elements are
+# block diagonal over the components: everything computed from the x component -- enc(x), the decoder tangent
+# J_dec(z_x)(L z_x), the decoded g z_x -- does not depend on the ODE.  The L-BFGS trainer evaluates hundreds of closures
+# on ONE fixed batch (train.py:626), so with a frozen autoencoder that half is computed once per batch and only the
+# f(x) component runs through the MLP per closure.  Opt-in: the caller passes the fixed batch as ``x_const``.
+# --------------------------------------------------------------------------------------------
+_CONST_HALF = {}
+
+
+def _diag_block(mat, n_comps):
+    """the common diagonal block of a block-diagonal (n_comps k, n_comps k) matrix, or None"""
+    k = mat.shape[-1] // n_comps
+    if k * n_comps != mat.shape[-1]:
+        return None
+    L = mat[:k, :k]
+    return L if torch.equal(mat, torch.block_diag(*([L] * n_comps))) else None
+
+
+def _split_ok(x_const, x_fx, autoencoder, generator, normalize, numpy):
+    from .autoencoder import AutoEncoder
+    if x_const is None or numpy or normalize != 'global' or not isinstance(autoencoder, AutoEncoder):
+        return False
+    if not isinstance(autoencoder.encoder, torch.nn.Sequential) or autoencoder.training:
+        return False
+    if x_fx.dim() != 3 or x_fx.shape[0] % x_fx.shape[1] != 0 or x_const.shape != x_fx[:, 0].shape:
+        return False
+    return not any(p.requires_grad for m in (autoencoder, generator) for p in m.parameters())
+
+
+def _by_rows(module_call, a, n_comps):
+    """an (B, k) batch through a module that expects (., n_comps, k): consecutive samples stand in for the components"""
+    return module_call(a.reshape(-1, n_comps, a.shape[-1])).reshape(a.shape[0], -1)
+
+
+def _const_half(kind, x_const, autoencoder, generator, blocks, zm, n_comps):
+    """cached per live batch tensor: (z_x, [decoder tangent | decoded g z_x per block])"""
+    key = (kind, x_const._version, id(autoencoder), id(generator), len(blocks))
+    hit = _CONST_HALF.get(kind)
+    if hit is None or hit[0]() is not x_const or hit[1] != key:
+        with torch.no_grad():
+            z0 = _by_rows(autoencoder.encode, x_const, n_comps) - zm
+            outs = []
+            for L in blocks:
+                if kind == 'i':
+                    t = _module_jvp(autoencoder.decoder, z0.reshape(-1, n_comps, z0.shape[-1]),
+                                    (z0 @ L.T).reshape(-1, n_comps, z0.shape[-1]), False)
+                    outs.append(t.reshape(x_const.shape[0], -1))
+                else:
+                    outs.append(_by_rows(autoencoder.decode, z0 @ L.T + zm, n_comps))
+        hit = (weakref.ref(x_const), key, z0, outs)
+        _CONST_HALF[kind] = hit
+    return hit[2], hit[3]
+
+
+# --------------------------------------------------------------------------------------------
 # S2: infinitesimal                                                   ref: model_utils.py:8-67
 # --------------------------------------------------------------------------------------------
 def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global', z_mean=None, relative=True,
-              require_grad=False, numpy=False):
+              require_grad=False, numpy=False, x_const=None):
     if numpy:
         x_fx = torch.from_numpy(x_fx).float().to(autoencoder.device)
         if z_mean is not None:
@@ -208,6 +264,23 @@ def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global
     jvp_fn = _jvp_fn(require_grad)
     autoencoder.eval()
     generator.eval()
+    if f is not None and _split_ok(x_const, x_fx, autoencoder, generator, normalize, numpy):
+        nc = x_fx.shape[1]
+        blocks = [_diag_block(v, nc) for v in generator.get_full_basis_list()]
+        if all(b is not None for b in blocks):
+            with torch.set_grad_enabled(require_grad):
+                zm = _z_mean(autoencoder, z_mean)
+                _, v_xs = _const_half('i', x_const, autoencoder, generator, blocks, zm, nc)
+                x, fx = x_fx[:, 0], x_fx[:, 1]
+                z1 = _by_rows(autoencoder.encode, fx, nc) - zm
+                loss = 0.0
+                for L, v_x in zip(blocks, v_xs):
+                    v_fx = _module_jvp(autoencoder.decoder, z1.reshape(-1, nc, z1.shape[-1]),
+                                       (z1 @ L.T).reshape(-1, nc, z1.shape[-1]), require_grad).reshape(fx.shape[0], -1)
+                    input_variation = f.tangent(x, v_x)[1] if isinstance(f, _EulerFlow) else jvp_fn(f, x, v_x)[1]
+                    err = torch.mean((input_variation - v_fx) ** 2)
+                    loss += err / torch.mean(input_variation ** 2) if relative else err
+            return loss
     with torch.set_grad_enabled(require_grad):
         loss = 0.0
         z = autoencoder.encode(x_fx)
@@ -241,7 +314,7 @@ def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global
 # S3: finite                                                         ref: model_utils.py:69-124
 # --------------------------------------------------------------------------------------------
 def symmreg_f(x_fx, autoencoder, generator, f, normalize='global', z_mean=None, relative=True, require_grad=False,
-              numpy=False):
+              numpy=False, x_const=None):
     autoencoder.eval()
     generator.eval()
     if numpy:
@@ -250,6 +323,22 @@ def symmreg_f(x_fx, autoencoder, generator, f, normalize='global', z_mean=None, 
             z_mean = torch.from_numpy(z_mean).float().to(generator.Li[0].device)
         if require_grad:
             raise ValueError('Cannot require grad when numpy=True.')
+    if _split_ok(x_const, x_fx, autoencoder, generator, normalize, numpy):
+        nc = x_fx.shape[1]
+        blocks = [_diag_block(g, nc) for g in generator.get_deterministic_group_elems()]
+        if all(b is not None for b in blocks):
+            with torch.set_grad_enabled(require_grad):
+                zm = _z_mean(autoencoder, z_mean)
+                _, g_xs = _const_half('f', x_const, autoencoder, generator, blocks, zm, nc)
+                fx = x_fx[:, 1]
+                z1 = _by_rows(autoencoder.encode, fx, nc) - zm
+                loss = 0.0
+                for G, g_x in zip(blocks, g_xs):
+                    g_fx = _by_rows(autoencoder.decode, z1 @ G.T + zm, nc)
+                    f_g_x = f(g_x)
+                    err = torch.mean((f_g_x - g_fx) ** 2)
+                    loss += err / torch.mean((f_g_x - fx) ** 2) if relative else err
+            return loss
     with torch.set_grad_enabled(require_grad):
         loss = 0.0
         z = autoencoder.encode(x_fx)

@@ -587,7 +587,7 @@ def train_SIGED_lbfgs(
                     forward_step = _EulerFlow(regressor, int_t, int_dt)
                     fx_pred = forward_step(x)
                     x_fx = torch.stack([x, fx_pred], dim=1)
-                    loss_sym_reg = symm_loss(x_fx, f=forward_step)
+                    loss_sym_reg = symm_loss(x_fx, f=forward_step, x_const=x)
                 elif sym_reg_type == 'r':
                     loss_sym_reg = symm_loss(x, h=regressor)
                 losses['loss_sym_reg'] = loss_sym_reg.detach()
@@ -736,7 +736,7 @@ def train_SIGED(
                 if w_sym_reg > 0:                          # the reference evaluates it even at weight 0 (logging only)
                     forward_step = _EulerFlow(regressor, int_t, int_dt)
                     x_fx = torch.stack([x, forward_step(x)], dim=1)
-                    loss_sym_reg = symm_loss(x_fx, f=forward_step)
+                    loss_sym_reg = symm_loss(x_fx, f=forward_step, x_const=x)
                     running['loss_sym_reg'].append(loss_sym_reg.item())
                 else:
                     loss_sym_reg = 0.0

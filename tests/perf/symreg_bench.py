@@ -54,9 +54,9 @@ def main():
         r.Xi.grad = None
         loss = r.mse_loss(x, dx)
         if kind == "i":
-            loss = loss + 0.1 * s_i(torch.stack([x, flow(x)], 1), f=flow)
+            loss = loss + 0.1 * s_i(torch.stack([x, flow(x)], 1), f=flow, x_const=x)     # as train_SIGED_lbfgs calls it
         elif kind == "f":
-            loss = loss + 0.1 * s_f(torch.stack([x, flow(x)], 1), f=flow)
+            loss = loss + 0.1 * s_f(torch.stack([x, flow(x)], 1), f=flow, x_const=x)
         elif kind == "r":
             loss = loss + 0.1 * s_r(x, h=r)
         loss.backward()

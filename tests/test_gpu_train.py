@@ -330,3 +330,29 @@ def test_caches_follow_the_tensor_object_not_its_address(S, golden):
     assert l2 == fresh and l2 != l1
     G2 = r.aug_gram(x2, y1)
     assert not np.allclose(G1, G2) and np.allclose(G2, S.get_engine().aug_gram(x2, y1, 2, 0).cpu().numpy())
+
+
+@pytest.mark.parametrize("tag,act,rep", [("relu_sim2", "ReLU", "(2,sim2)"), ("tanh_learn", "Tanh", "(2,1,2)")])
+def test_constant_half_of_the_symmetry_regularisers_with_gradients(S, golden, tag, act, rep):
+    """S2 / S3 closures with the x component of the autoencoder work cached per batch (x_const) against the all-at-once form:
+    same loss, same dloss/dXi through the fused Euler tangent kernels."""
+    MU = S.model_utils
+    g = golden("f6_symreg")
+    ae = load_fixture_autoencoder(g, tag, act, DEV)
+    gen = load_fixture_generator(g, tag, rep, DEV)
+    for p in list(ae.parameters()) + list(gen.parameters()):
+        p.requires_grad = False
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    x = t(g[f"{tag}_x"]).to(DEV)[:256].contiguous()
+    for kind, fn in (("i", MU.symmreg_i), ("f", MU.symmreg_f)):
+        out = []
+        for split in (False, True):
+            r = S.SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.05, device=DEV)
+            r.Xi.data = t(g[f"{tag}_Xi"]).to(DEV)
+            flow = MU._EulerFlow(r, 0.05, 0.01)
+            x_fx = torch.stack([x, flow(x)], dim=1)
+            loss = fn(x_fx, ae, gen, f=flow, require_grad=True, **({"x_const": x} if split else {}))
+            loss.backward()
+            out.append((loss.item(), r.Xi.grad.detach().cpu().clone()))
+        assert out[1][0] == pytest.approx(out[0][0], rel=2e-5), kind
+        assert (out[1][1] - out[0][1]).abs().max() <= 2e-4 * out[0][1].abs().max(), kind

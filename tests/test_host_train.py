@@ -161,3 +161,28 @@ def test_forward_mode_mlp_jvp_equals_functional_jvp(act, bn, ortho):
         assert torch.allclose(a[0], b[0], atol=1e-12) and torch.allclose(a[1], b[1], atol=1e-10)
     ae.train()                                                  # train-mode batch norm couples the samples: not covered
     assert (mlp_jvp(ae.encoder, torch.randn(5, 2, 3, dtype=torch.float64), torch.randn(5, 2, 3, dtype=torch.float64)) is None) == bn
+
+
+@pytest.mark.parametrize("tag,act,rep", [("relu_sim2", "ReLU", "(2,sim2)"), ("tanh_learn", "Tanh", "(2,1,2)")])
+def test_constant_half_of_the_symmetry_regularisers(golden, tag, act, rep):
+    """S2 / S3 with the Xi-independent x component computed once per batch (x_const=...) equal the all-at-once evaluation
+    (values here; gradients in tests/test_gpu_train.py), and the cache follows the batch tensor."""
+    from symode_amd import model_utils as MU
+    g = golden("f6_symreg")
+    ae = load_fixture_autoencoder(g, tag, act)
+    gen = load_fixture_generator(g, tag, rep)
+    for p in list(ae.parameters()) + list(gen.parameters()):
+        p.requires_grad = False
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    r = SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.05, device="cpu", engine=OracleEngine())
+    r.Xi.data = t(g[f"{tag}_Xi"]).clone()
+    flow = MU._EulerFlow(r, 0.05, 0.01)
+    x = t(g[f"{tag}_x"])[:256].contiguous()
+    for kind, fn in (("i", MU.symmreg_i), ("f", MU.symmreg_f)):
+        for batch in (x, (x * 1.1).contiguous()):                  # a second batch must not reuse the first one's half
+            with torch.no_grad():
+                x_fx = torch.stack([batch, flow(batch)], dim=1)
+                a = fn(x_fx, ae, gen, f=flow, x_const=batch).item()
+                b = fn(x_fx, ae, gen, f=flow).item()
+            assert a == pytest.approx(b, rel=2e-5), kind
+            assert MU._CONST_HALF[kind][0]() is batch
