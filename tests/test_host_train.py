@@ -186,3 +186,19 @@ def test_constant_half_of_the_symmetry_regularisers(golden, tag, act, rep):
                 b = fn(x_fx, ae, gen, f=flow).item()
             assert a == pytest.approx(b, rel=2e-5), kind
             assert MU._CONST_HALF[kind][0]() is batch
+
+
+def test_mlp_split_autoencoder_layout():
+    """'mlp_split' (reference model.py:62-70): two independent MLPs on the halves of the last axis, state_dict prefixes
+    encoder.model{1,2}.layers.* / decoder.model{1,2}.layers.*."""
+    from symode_amd.autoencoder import AutoEncoder
+    ae = AutoEncoder(ae_arch="mlp_split", input_dim=6, hidden_dim=8, latent_dim=2, n_layers=2, n_comps=2, activation="ReLU",
+                     activation_args=[], batch_norm=False, ortho_ae=False)
+    keys = set(ae.state_dict())
+    assert {"encoder.model1.layers.0.weight", "encoder.model2.layers.4.0.weight", "decoder.model1.layers.0.weight"} <= keys
+    x = torch.randn(5, 2, 12)
+    z, xhat = ae(x)
+    assert z.shape == (5, 2, 4) and xhat.shape == (5, 2, 12)
+    x2 = x.clone()
+    x2[..., 6:] += 1.0                                           # the second half only reaches the second model
+    assert torch.equal(ae.encode(x2)[..., :2], z[..., :2]) and not torch.equal(ae.encode(x2)[..., 2:], z[..., 2:])
