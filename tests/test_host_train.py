@@ -195,7 +195,7 @@ def test_mlp_split_autoencoder_layout():
     ae = AutoEncoder(ae_arch="mlp_split", input_dim=6, hidden_dim=8, latent_dim=2, n_layers=2, n_comps=2, activation="ReLU",
                      activation_args=[], batch_norm=False, ortho_ae=False)
     keys = set(ae.state_dict())
-    assert {"encoder.model1.layers.0.weight", "encoder.model2.layers.4.0.weight", "decoder.model1.layers.0.weight"} <= keys
+    assert {"encoder.model1.layers.0.weight", "encoder.model2.layers.5.0.weight", "decoder.model1.layers.0.weight"} <= keys
     x = torch.randn(5, 2, 12)
     z, xhat = ae(x)
     assert z.shape == (5, 2, 4) and xhat.shape == (5, 2, 12)
