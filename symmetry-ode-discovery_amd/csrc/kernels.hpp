@@ -86,7 +86,7 @@ inline bool vec_ok(const void* p, long n, int d, long S) {
 #define SYMODE_ROWS_XI_SGPR 1       // loss_grad_rows_kernel: its row of Xi in SGPRs (1) or VGPRs (0); measured 555 vs 587 us at p = 35
 #endif
 constexpr int VGPR_XI_MAX = 48;     // up to here the masked coefficients simply stay in VGPRs (see load_xi)
-constexpr int SGPR_XI_MAX = 64;     // largest D*P kept in SGPRs (the wave has ~100 of them: d = 2 up to order 5, d = 3 order 3, d = 4 order 2)
+constexpr int SGPR_XI_MAX = 64;     // VGPR_XI_MAX < D*P <= this: Xi in SGPRs (the wave has ~100 of them: d = 3 order 3, d = 4 order 2)
 
 // Masked coefficients of problem s into registers (uniform across the block -> scalar loads).
 template <class Lib>
@@ -350,8 +350,9 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 //   6 packed fp32 (below); 8 LDS-DMA ring.
 // Measured on MI355X, S = 2048 x 125000 points, d = 2 (round 1, algorithmic bytes / launch incl. finalize):
 //   order 5: 0 -> 4.8 TB/s, 4 -> 5.4, 5 -> 5.55, 7 -> 5.65 TB/s;  order 3: 0 -> 5.6, 4 -> 6.35, 5 and 7 -> 6.45 TB/s.
-// With Xi in SGPRs (load_xi) the order-5 kernel needs 126 VGPRs (4 waves/SIMD); keeping Xi in VGPRs (146, 3 waves)
-// measured the same, as did grid widths 4096-16384: nothing but the two pipes themselves is left to tune.
+// With the masked Xi in VGPRs the order-5 ring kernel needs 166 VGPRs (3 waves/SIMD); handing Xi to SGPRs (126 VGPRs,
+// 4 waves) measured 1.5 % slower -- an SGPR operand costs issue time -- and grid widths 4096-16384 measured the same:
+// nothing but the two pipes themselves is left to tune.
 // Why order 5 stops there: 108 VALU ops per point = 422 K wave-instructions per SIMD per launch, and a SIMD with 3
 // resident waves retires one every 1.23 ns (tools/micro/valu_rate.hip), i.e. 0.52 ms of VALU beside 0.52-0.64 ms of
 // HBM stream in a 0.73 ms launch: both pipes are > 70 % busy.  Forms with sched_barrier between points were slower or
@@ -1329,9 +1330,9 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // contiguous slab per workgroup: 1 = for one big problem, 2 = also inside every problem of a batch
     const bool seg = (seg_env == 1 && S == 1 && gx >= 64) || (seg_env == 2 && gx >= 2);
     const dim3 grid(gx, (unsigned)S), block(BLOCK);
-    // The register-ring / prefetch / packed forms pay only where the library leaves registers for them: d = 2 with Xi
-    // in SGPRs (every task the reference ships).  Larger libraries (d = 3, 4 at orders 3-4: 390-430 VGPRs already)
-    // would spill, so they keep the two-chunk form and the experimental variants are not even instantiated for them.
+    // The register-ring / prefetch / packed forms pay only where the library leaves registers for them: d = 2 (every
+    // task the reference ships).  Mid-size libraries keep the two-chunk form, the largest ones (D*P > SGPR_XI_MAX) the
+    // row-per-wave kernel; the experimental variants are not even instantiated for them.
     constexpr bool TUNED = (Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX);
     constexpr bool ROWS = (Lib::D >= 2) && (Lib::D * Lib::P > SGPR_XI_MAX);
     static const int rows_env = getenv("SYMODE_ROW_SPLIT") ? atoi(getenv("SYMODE_ROW_SPLIT")) : 1;
