@@ -17,7 +17,6 @@ residual is differentiable w.r.t. z -- runs on the HIP engine.
 from __future__ import annotations
 
 import os
-from copy import deepcopy
 
 import numpy as np
 import torch
