@@ -17,7 +17,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
 
 import symode_amd
 from symode_amd import dataset as D, parser_utils
@@ -46,7 +45,8 @@ def main():
     args["L_list"] = [L[:2, :2].detach().cpu() for L in gen.get_full_basis_list()]
     with contextlib.redirect_stdout(io.StringIO()):
         reg = symode_amd.SINDyRegression(**args).to(dev)
-    tl, vl = DataLoader(tr, batch_size=args["batch_size"], shuffle=True), DataLoader(va, batch_size=args["batch_size"])
+    tl = D.make_loader(tr, args["batch_size"], True, dev)          # as main.py builds them: device-resident, one gather per batch
+    vl = D.make_loader(va, args["batch_size"], False, dev)
     run = lambda n: symode_amd.train.train_lassi(autoencoder=ae, discriminator=disc, generator=gen, regressor=reg,  # noqa: E731
                                                   regressor_dst=None, train_loader=tl, test_loader=vl, **dict(args, num_epochs=n))
     with contextlib.redirect_stdout(io.StringIO()):
