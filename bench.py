@@ -148,7 +148,9 @@ def main():
     def step():
         return clos.evaluate(beta, const)
 
-    for _ in range(a.warmup):
+    # W untimed warm-up steps as asked, topped up to >= 20 so that a small W does not leave the first timed launches on
+    # ramping clocks (the timed region below is exactly K steps either way)
+    for _ in range(max(a.warmup, 20)):
         step()
     torch.cuda.synchronize()
     if use_dist:
