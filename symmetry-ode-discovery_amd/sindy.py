@@ -307,7 +307,8 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
     if mask.all() and not regressor.constraint:
         W, _ = lstsq_normal(Gtt, Gty, N + p, driver)                       # (p, d); sindy.py:288, 300
         res = np.array([G[p + j, p + j] - 2 * W[:, j] @ Gty[:, j] + W[:, j] @ Gtt @ W[:, j] for j in range(d)])
-        regressor.Xi.data = torch.from_numpy(W.T.copy()).float().to(dev)
+        xi_host = W.T.astype(np.float32)                                    # what .float() makes of it on the device
+        regressor.Xi.data = torch.from_numpy(xi_host.copy()).to(dev)
         residual = res.mean()
     else:
         # block-diagonal system over all equations, equation-major flattening (sindy.py:270-274)
@@ -322,7 +323,8 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
             w, _ = lstsq_normal(Gm, cm, m_rows, driver)
             new_coef = np.zeros((d, p))
             new_coef[mask] = w                                              # sindy.py:296-298
-            regressor.Xi.data = torch.from_numpy(new_coef).float().to(dev)
+            xi_host = new_coef.astype(np.float32)
+            regressor.Xi.data = torch.from_numpy(xi_host.copy()).to(dev)
             residual = yy - 2 * w @ cm + w @ Gm @ w
         else:
             Q = regressor.Q.detach().cpu().double().numpy()
@@ -345,12 +347,22 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
                 regressor.beta.data = torch.from_numpy(full[:-d].copy()).float().to(dev)
                 regressor.const.data = torch.from_numpy(full[-d:].copy()).float().view(-1, 1).to(dev)
             residual = yy - 2 * b @ cq + b @ Gq @ b
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)
     # coefficients of THIS solve (support = the mask it was solved on), before the new threshold is applied
-    xi_sol = ((regressor.get_Xi() if regressor.constraint else regressor.Xi).detach() * prev_mask).contiguous()
-    regressor.set_threshold(st_threshold)                                   # sindy.py:312
-    converged = torch.allclose(prev_mask, regressor.mask)                   # sindy.py:313
+    xi_sol = None
+    if needs_grad:
+        xi_sol = ((regressor.get_Xi() if regressor.constraint else regressor.Xi).detach() * prev_mask).contiguous()
+    if regressor.constraint:
+        regressor.set_threshold(st_threshold)                               # sindy.py:312 (Xi = Q beta is a device product)
+        converged = torch.allclose(prev_mask, regressor.mask)               # sindy.py:313
+    else:
+        # the solution was just made on the host: threshold it there (same fp32 values, same strict >, sindy.py:192-194)
+        # and upload the mask -- instead of three device launches and a synchronising allclose
+        new_mask = np.logical_and(np.abs(xi_host) > np.float32(st_threshold), mask)
+        regressor.mask.data = torch.from_numpy(new_mask.astype(np.float32)).to(dev)
+        converged = bool(np.array_equal(new_mask, mask))
     value = torch.tensor(residual / N, dtype=torch.float32, device=dev)
-    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+    if needs_grad:
         # lm.residuals is per right-hand side: d columns for the full-mask solve, one for the flattened system
         per_col = mask.all() and not regressor.constraint
         scale = 1.0 / (N * (d if per_col else 1))
