@@ -45,6 +45,10 @@ int main(void) {
     CHECK_HIP(hipMalloc((void**)&loss, sizeof(float)));
     CHECK_HIP(hipMalloc((void**)&grad, sizeof(float) * d * p));
     CHECK_HIP(hipMalloc(&ws, ws_bytes));
+    if (symode_workspace_init(ws, ws_bytes, NULL) != SYMODE_OK) {      /* once per allocation */
+        fprintf(stderr, "symode_workspace_init failed\n");
+        return 1;
+    }
     CHECK_HIP(hipMemcpy(x, hx, sizeof(float) * n * d, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dx, hdx, sizeof(float) * n * d, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(xi, hxi, sizeof(float) * d * p, hipMemcpyHostToDevice));

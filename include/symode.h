@@ -49,6 +49,14 @@ int symode_lib_size(int d, int order, int flags);
  * The same buffer serves symode_loss_grad / symode_aug_gram / the symreg entry points. */
 size_t symode_workspace_bytes(int d, int order, int flags, long n_problems, long n);
 
+/* One-time preparation of a freshly allocated workspace (enqueued on `stream`): writes the header the
+ * one-launch reductions keep their "last workgroup done" tickets in.  The tickets reset themselves, so one
+ * call per allocation is enough; a workspace that never saw this call makes the reductions return NaN
+ * (never stale numbers).  A workspace must not be shared by calls that run concurrently on different streams.
+ * replaces: nothing in the reference (its reductions are torch ops); it exists so that the closure body
+ * train.py:663-664 + 689 is ONE kernel launch at the 50x2500x2 shape. */
+int symode_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+
 /* Theta(x) materialised: theta_out (n, p).
  * replaces: SINDyRegression.eval_Theta_at, sindy.py:201-203 (term functions sindy.py:7-30) */
 int symode_theta(const float* x, long n, int d, int order, int flags, float* theta_out, void* stream);

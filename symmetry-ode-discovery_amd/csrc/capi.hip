@@ -31,6 +31,11 @@ inline int gram_grid(long n, long S) {
     return g > cap ? (int)cap : g;
 }
 
+inline int small_grid_cap() {
+    const char* e = getenv("SYMODE_SMALL_GRID");
+    return e ? atoi(e) : 128;
+}
+
 // points per 16-byte chunk step (points.hpp, Chunk<D>::PPT)
 inline int ppt_for(int d) { return d == 2 ? 2 : d == 4 ? 1 : 4; }
 
@@ -43,14 +48,14 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
     const size_t g_red = (size_t)grid_x_for(n, S, 1);   // widest grid any reduction uses
     const size_t a = (size_t)S * g_red * nacc;
     const size_t b = (size_t)S * g_red * gram_partial;
-    return a > b ? a : b;
+    return (size_t)WS_HEADER_DOUBLES + (a > b ? a : b);      // [magic + tickets | partial rows]
 }
 
 }  // namespace
 
 extern "C" {
 
-int symode_abi_version(void) { return 1; }
+int symode_abi_version(void) { return 2; }
 
 const char* symode_error_string(int code) {
     switch (code) {
@@ -73,6 +78,16 @@ size_t symode_workspace_bytes(int d, int order, int flags, long n_problems, long
     const LibOps* ops = find_ops(d, order, flags);
     if (!ops || n_problems < 1 || n < 0) return 0;
     return workspace_doubles(ops, n_problems, n) * sizeof(double);
+}
+
+int symode_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace) return SYMODE_E_NULLPTR;
+    if (misaligned(workspace, 8)) return SYMODE_E_ALIGN;
+    if (workspace_bytes < (size_t)WS_HEADER_DOUBLES * sizeof(double)) return SYMODE_E_WORKSPACE;
+    const long words = WS_HEADER_DOUBLES;
+    workspace_init_kernel<0><<<dim3((unsigned)((words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream>>>(
+        (unsigned long long*)workspace, words);
+    return (int)hipGetLastError();
 }
 
 #define SYMODE_GET_OPS()                              \
@@ -132,7 +147,13 @@ int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, i
         misaligned(grad_out, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
-    const int gx = grid_x_for(n, n_problems, ppt_for(d));
+    int gx = grid_x_for(n, n_problems, ppt_for(d));
+    // a single latency-bound problem: the last workgroup adds gx partial rows alone, so fewer, longer workgroups win
+    // (SYMODE_SMALL_GRID overrides the cap for tuning runs; 0 = no cap)
+    if (n_problems == 1 && gx <= 512) {
+        const int cap = small_grid_cap();
+        if (cap > 0 && gx > cap) gx = cap;
+    }
     return (int)ops->loss_grad(x, dx, n_problems, n, xi, mask, inv_count, loss_out, grad_out, (double*)workspace, gx,
                                (hipStream_t)stream);
 }

@@ -154,9 +154,10 @@ __global__ __launch_bounds__(BLOCK) void gram_finalize_kernel(const double* __re
 template <class Lib>
 hipError_t launch_aug_gram(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
                            int gx, hipStream_t st) {
-    aug_gram_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, idx, ws);
+    double* part = ws + WS_HEADER_DOUBLES;             // the header (magic, tickets) belongs to the one-launch reductions
+    aug_gram_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, idx, part);
     SYMODE_LAUNCH_CHECK();
-    gram_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, gram);
+    gram_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(part, gx, gram);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -284,29 +284,49 @@ __global__ __launch_bounds__(BLOCK) void odeint_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // Reduction epilogue shared by every "scalar loss + (d,p) gradient" kernel.
-//   pass 1: each block leaves NACC fp64 partial sums in ws[(s*G + b)*NACC + k];
-//   pass 2: one block per problem adds the G partials in fixed order (deterministic),
-//           scales, masks, rounds to fp32.
+//   each block leaves NACC fp64 partial sums in part[(s*G + b)*NACC + k];
+//   ONE launch (default): the block whose ticket comes last adds the G rows in fixed order, scales, masks,
+//       rounds to fp32 and resets the ticket -- "last block done", no second kernel;
+//   two launches (SYMODE_FUSED_FINALIZE=0, and the row-per-wave kernel): finalize_kernel does the same sums.
+// Both orders of addition are identical, so the two paths are bit-identical (tests/test_gpu_kernels.py).
+//
+// Cross-workgroup hand-off without fences (MI355X_MICROARCH.md, "Valid forms", table row 1): the partial row is
+// written with agent-scope (sc1, write-through) stores, every storing wave drains them (s_waitcnt vmcnt(0)), a
+// workgroup barrier, then ONE lane adds to the problem's ticket; the block that reads G-1 back loads the rows with
+// agent-scope (sc1, L1-bypassing) loads after a barrier its adding wave joins.  The ticket lives in the header of the
+// caller's workspace (zeroed once by symode_workspace_init, self-resetting afterwards); a workspace that was never
+// initialised is recognised by its magic word and answered with NaN outputs instead of stale ones.
 // ---------------------------------------------------------------------------------------
-template <int NACC>
-__device__ __forceinline__ void emit_partials(float (&acc)[NACC], double* __restrict__ ws) {
-    __shared__ float lds[reduce_lds_floats(BLOCK)];
-    double* dst = ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * NACC;
-    block_reduce_emit_lds<NACC, BLOCK>(acc, lds, [&](int k, double v) { dst[k] = v; });
+constexpr unsigned long long WS_MAGIC = 0x53594d4f44453032ull;      // "SYMODE02"
+constexpr long WS_MAX_PROBLEMS = 65536;                              // tickets in the header (grid.y limit is 65535)
+constexpr long WS_HEADER_DOUBLES = 8 + WS_MAX_PROBLEMS / 2;          // [magic, 7 reserved | uint32 tickets] in front of the partials
+
+struct Finish {
+    unsigned long long* header;      // workspace base: header[0] = magic, tickets behind it
+    const float* mask;               // (S, NACC-1) or null
+    float loss_scale, grad_scale;
+    float* loss;                     // (S) or null
+    float* grad;                     // (S, NACC-1)
+    int fused;                       // 1: last-block finalisation inside this launch
+};
+
+__device__ __forceinline__ unsigned* ws_tickets(unsigned long long* header) {
+    return reinterpret_cast<unsigned*>(header + 8);
 }
 
-// out[0] = loss_scale * sum_0 ; grad[k-1] = grad_scale * sum_k * mask[k-1]
-// (a template only so that the header-defined kernel has vague linkage across the per-D TUs)
-template <int TAG = 0>
-__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restrict__ ws, int G, int nacc,
-                                                         const float* __restrict__ mask, float loss_scale,
-                                                         float grad_scale, float* __restrict__ loss,
-                                                         float* __restrict__ grad) {
-    // thread (part, lane): value k = k0 + lane, blocks g = part, part + 4, ... (coalesced rows of the
-    // partial matrix); the 4 parts are combined in fixed order through LDS.
-    __shared__ double comb[BLOCK];
-    const long s = blockIdx.x;
-    const double* src = ws + s * (long)G * nacc;
+// Sum the G partial rows of problem s in fixed order and write the outputs: thread (part, lane) adds rows
+// part, part + 4, ... of value k = k0 + lane; the 4 parts are combined in fixed order through LDS.
+// SC1: rows come from other workgroups of the SAME launch (agent-scope loads), else plain loads.
+template <bool SC1>
+__device__ __forceinline__ void combine_rows(const double* __restrict__ src, int G, int nacc, long s,
+                                             const float* __restrict__ mask, float loss_scale, float grad_scale,
+                                             float* __restrict__ loss, float* __restrict__ grad, double* comb) {
+    auto ld = [&](long i) -> double {
+        if constexpr (SC1)
+            return __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            return src[i];
+    };
     const int lane = threadIdx.x & (WAVE - 1), part = threadIdx.x / WAVE;
     for (int k0 = 0; k0 < nacc; k0 += WAVE) {
         const int k = k0 + lane;
@@ -317,11 +337,11 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
             for (; g + (U - 1) * NP_ < G; g += U * NP_) {      // 16 independent loads in flight, added in order
                 double t[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) t[u] = src[(long)(g + u * NP_) * nacc + k];
+                for (int u = 0; u < U; ++u) t[u] = ld((long)(g + u * NP_) * nacc + k);
 #pragma unroll
                 for (int u = 0; u < U; ++u) v += t[u];
             }
-            for (; g < G; g += NP_) v += src[(long)g * nacc + k];
+            for (; g < G; g += NP_) v += ld((long)g * nacc + k);
         }
         if (k0 > 0) __syncthreads();
         comb[threadIdx.x] = v;
@@ -337,6 +357,66 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
             }
         }
     }
+}
+
+template <int NACC>
+__device__ __forceinline__ void emit_partials(float (&acc)[NACC], double* __restrict__ part, const Finish& fin) {
+    __shared__ float lds[reduce_lds_floats(BLOCK)];
+    __shared__ unsigned last_flag;
+    const long s = blockIdx.y;
+    const int G = gridDim.x;
+    double* dst = part + (s * G + blockIdx.x) * NACC;
+    if (!fin.fused) {
+        block_reduce_emit_lds<NACC, BLOCK>(acc, lds, [&](int k, double v) { dst[k] = v; });
+        return;
+    }
+    if (fin.header[0] != WS_MAGIC) {                     // workspace never initialised: fail loudly, touch no ticket
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (fin.loss != nullptr) fin.loss[s] = __builtin_nanf("");
+            fin.grad[s * (NACC - 1)] = __builtin_nanf("");
+        }
+        return;
+    }
+    block_reduce_emit_lds<NACC, BLOCK>(acc, lds, [&](int k, double v) {
+        __hip_atomic_store(dst + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave has its row out before the ticket
+    __syncthreads();
+    unsigned* ticket = ws_tickets(fin.header) + s;
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (t == (unsigned)(G - 1)) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_flag == 0u) return;
+    double* comb = reinterpret_cast<double*>(lds);       // BLOCK doubles fit in the staging area
+    static_assert(sizeof(float) * reduce_lds_floats(BLOCK) >= sizeof(double) * BLOCK, "LDS too small for the combine");
+    combine_rows<true>(part + s * (long)G * NACC, G, NACC, s, fin.mask, fin.loss_scale, fin.grad_scale, fin.loss, fin.grad,
+                       comb);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
+// out[0] = loss_scale * sum_0 ; grad[k-1] = grad_scale * sum_k * mask[k-1]
+// (a template only so that the header-defined kernel has vague linkage across the per-D TUs)
+template <int TAG = 0>
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restrict__ ws, int G, int nacc,
+                                                         const float* __restrict__ mask, float loss_scale,
+                                                         float grad_scale, float* __restrict__ loss,
+                                                         float* __restrict__ grad) {
+    __shared__ double comb[BLOCK];
+    const long s = blockIdx.x;
+    combine_rows<false>(ws + s * (long)G * nacc, G, nacc, s, mask, loss_scale, grad_scale, loss, grad, comb);
+}
+
+template <int TAG = 0>
+__global__ __launch_bounds__(BLOCK) void workspace_init_kernel(unsigned long long* header, long n_words) {
+    const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n_words) header[i] = (i == 0) ? WS_MAGIC : 0ull;
+}
+
+inline bool fused_finalize_enabled() {
+    const char* e = getenv("SYMODE_FUSED_FINALIZE");      // read per call: tests flip it inside one process
+    return !(e && e[0] == '0');
 }
 
 // ---------------------------------------------------------------------------------------
@@ -362,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restric
 template <class Lib, int VARIANT>
 __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, const float* __restrict__ dx, long N, bool vec,
                                                const float* __restrict__ xi, const float* __restrict__ mask,
-                                               double* __restrict__ ws, const bool SEGMENTED) {
+                                               double* __restrict__ ws, const Finish& fin, const bool SEGMENTED) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
     constexpr bool NT = (VARIANT == 4 || VARIANT == 5 || VARIANT == 7);
     const long s = blockIdx.y;
@@ -581,7 +661,7 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
     } else {
         for (long n = tid; n < N; n += nthreads) point(n);
     }
-    emit_partials<NACC>(acc, ws);
+    emit_partials<NACC>(acc, ws, fin);
 }
 
 // Packed-fp32 form of K1 (VARIANT 6, D <= 2; an A/B knob, not the default).
@@ -600,7 +680,7 @@ template <class Lib>
 __device__ __forceinline__ void loss_grad_body_packed(const float* __restrict__ x, const float* __restrict__ dx, long N,
                                                       bool vec, const float* __restrict__ xi,
                                                       const float* __restrict__ mask, double* __restrict__ ws,
-                                                      const bool SEGMENTED) {
+                                                      const Finish& fin, const bool SEGMENTED) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
     constexpr int JP = D / 2;
     constexpr bool ODD = (D % 2) != 0;
@@ -758,18 +838,18 @@ __device__ __forceinline__ void loss_grad_body_packed(const float* __restrict__ 
         }
         if constexpr (ODD) acc[1 + JL * P + k] = accl[k].x + accl[k].y;
     }
-    emit_partials<NACC>(acc, ws);
+    emit_partials<NACC>(acc, ws, fin);
 }
 
 template <class Lib, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                           long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, double* __restrict__ ws,
-                                                          bool segmented) {
+                                                          Finish fin, bool segmented) {
     if constexpr (VARIANT == 6)
-        loss_grad_body_packed<Lib>(x, dx, N, vec, xi, mask, ws, segmented);
+        loss_grad_body_packed<Lib>(x, dx, N, vec, xi, mask, ws, fin, segmented);
     else
-        loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws, segmented);
+        loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws, fin, segmented);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -782,7 +862,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
                                                               const float* __restrict__ xi,
                                                               const float* __restrict__ mask,
                                                               const float* __restrict__ Lg, int n_gen,
-                                                              double* __restrict__ ws) {
+                                                              double* __restrict__ ws, Finish fin) {
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NACC = 1 + D * P;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -844,7 +924,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
             load_point<D>(z, n, zp);
             one(zp);
         });
-    emit_partials<NACC>(acc, ws);
+    emit_partials<NACC>(acc, ws, fin);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -858,7 +938,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
                                                                 const float* __restrict__ jgx, int n_g, long N,
                                                                 const float* __restrict__ xi,
                                                                 const float* __restrict__ mask,
-                                                                double* __restrict__ ws) {
+                                                                double* __restrict__ ws, Finish fin) {
     constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -902,7 +982,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
                 for (int k = 0; k < P; ++k) acc[1 + j * P + k] += jtu[j] * th[k] - u[j] * thg[k];
         }
     }
-    emit_partials<NACC>(acc, ws);
+    emit_partials<NACC>(acc, ws, fin);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -913,7 +993,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
 template <class Lib>
 __global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x, const float* __restrict__ g, long N,
                                                     const float* __restrict__ xi, const float* __restrict__ mask,
-                                                    float* __restrict__ grad_x, double* __restrict__ ws) {
+                                                    float* __restrict__ grad_x, double* __restrict__ ws, Finish fin) {
     constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -943,7 +1023,7 @@ __global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x,
             store_point<D>(grad_x, n, bx);
         }
     }
-    emit_partials<NACC>(acc, ws);
+    emit_partials<NACC>(acc, ws, fin);
 }
 
 // out = Theta(x) Xi_m^T and jv = (J_Theta(x) v) Xi_m^T in one pass (forward-mode tangent).
@@ -975,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict_
                                                         const float* __restrict__ g_jv, long N,
                                                         const float* __restrict__ xi, const float* __restrict__ mask,
                                                         float* __restrict__ grad_x, float* __restrict__ grad_v,
-                                                        double* __restrict__ ws) {
+                                                        double* __restrict__ ws, Finish fin) {
     constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -1011,7 +1091,7 @@ __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict_
         store_point<D>(grad_x, n, bx);
         store_point<D>(grad_v, n, bv);
     }
-    emit_partials<NACC>(acc, ws);
+    emit_partials<NACC>(acc, ws, fin);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1121,7 +1201,7 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __res
                                                               const float* __restrict__ xi,
                                                               const float* __restrict__ mask, int n_steps, float dt,
                                                               float* __restrict__ grad_x, float* __restrict__ grad_v,
-                                                              double* __restrict__ ws) {
+                                                              double* __restrict__ ws, Finish fin) {
     constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -1168,7 +1248,7 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __res
         store_point<D>(grad_x, n, ax);
         store_point<D>(grad_v, n, at);
     }
-    emit_partials<NACC>(acc, ws);
+    emit_partials<NACC>(acc, ws, fin);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1312,6 +1392,20 @@ __global__ __launch_bounds__(Lib::D* WAVE) void loss_grad_rows_kernel(const floa
     }
 }
 
+// `ws` of every launcher below is the caller's workspace base: [header | partials].
+inline Finish make_finish(double* ws, const float* mask, float loss_scale, float grad_scale, float* loss, float* grad) {
+    return Finish{reinterpret_cast<unsigned long long*>(ws), mask, loss_scale, grad_scale, loss, grad,
+                  fused_finalize_enabled() ? 1 : 0};
+}
+
+// second launch of the two-launch path
+inline hipError_t launch_finalize(const Finish& fin, double* part, long S, int gx, int nacc, hipStream_t st) {
+    if (fin.fused) return hipSuccess;
+    finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(part, gx, nacc, fin.mask, fin.loss_scale, fin.grad_scale,
+                                                               fin.loss, fin.grad);
+    return hipGetLastError();
+}
+
 template <class Lib>
 hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, const float* xi, const float* mask,
                             float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
@@ -1336,14 +1430,15 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     constexpr bool TUNED = (Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX);
     constexpr bool ROWS = (Lib::D >= 2) && (Lib::D * Lib::P > SGPR_XI_MAX);
     static const int rows_env = getenv("SYMODE_ROW_SPLIT") ? atoi(getenv("SYMODE_ROW_SPLIT")) : 1;
+    double* part = ws + WS_HEADER_DOUBLES;
+    Finish fin = make_finish(ws, mask, inv_count, 2.0f * inv_count, loss, grad);
     if constexpr (ROWS) {
         if (rows_env != 0) {
             // a workgroup covers 64 points per step: give it as many steps as the thread-per-point form has
-            loss_grad_rows_kernel<Lib><<<grid, dim3(Lib::D * WAVE), 0, st>>>(x, dx, n, xi, mask, ws);
+            loss_grad_rows_kernel<Lib><<<grid, dim3(Lib::D * WAVE), 0, st>>>(x, dx, n, xi, mask, part);
             SYMODE_LAUNCH_CHECK();
-            finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv_count, 2.0f * inv_count, loss, grad);
-            SYMODE_LAUNCH_CHECK();
-            return hipSuccess;
+            fin.fused = 0;                              // D waves per workgroup: this form keeps the second launch
+            return launch_finalize(fin, part, S, gx, NACC, st);
         }
     }
     int variant = loss_grad_variant();
@@ -1351,60 +1446,57 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     if (!TUNED && variant != 0) variant = 4;
     if constexpr (TUNED) {
         switch (variant) {
-            case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-            case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-            case 5: loss_grad_kernel<Lib, 5><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-            case 6: loss_grad_kernel<Lib, 6><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-            case 7: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-            case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
-            default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg); break;
+            case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            case 5: loss_grad_kernel<Lib, 5><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            case 6: loss_grad_kernel<Lib, 6><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            case 7: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
         }
     } else {
         if (variant == 4)
-            loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
+            loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg);
         else
-            loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, ws, seg);
+            loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg);
     }
     SYMODE_LAUNCH_CHECK();
-    finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv_count, 2.0f * inv_count, loss,
-                                                               grad);
-    SYMODE_LAUNCH_CHECK();
-    return hipSuccess;
+    return launch_finalize(fin, part, S, gx, NACC, st);
 }
 
 template <class Lib>
 hipError_t launch_symreg_linear(const float* z, long n, const float* xi, const float* mask, const float* L, int n_gen,
                                 float* loss, float* grad, double* ws, int gx, hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
+    double* part = ws + WS_HEADER_DOUBLES;
+    const Finish fin = make_finish(ws, mask, 1.0f, 2.0f, loss, grad);
     symreg_linear_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(z, n, vec_ok(z, n, Lib::D, 1), xi, mask, L, n_gen,
-                                                                  ws);
+                                                                  part, fin);
     SYMODE_LAUNCH_CHECK();
-    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 1.0f, 2.0f, loss, grad);
-    SYMODE_LAUNCH_CHECK();
-    return hipSuccess;
+    return launch_finalize(fin, part, 1, gx, NACC, st);
 }
 
 template <class Lib>
 hipError_t launch_symreg_reversed(const float* x, const float* gxp, const float* jgx, int n_g, long n, const float* xi,
                                   const float* mask, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
-    symreg_reversed_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, gxp, jgx, n_g, n, xi, mask, ws);
-    SYMODE_LAUNCH_CHECK();
+    double* part = ws + WS_HEADER_DOUBLES;
     const float inv = 1.0f / ((float)n * (float)Lib::D);
-    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, inv, 2.0f * inv, loss, grad);
+    const Finish fin = make_finish(ws, mask, inv, 2.0f * inv, loss, grad);
+    symreg_reversed_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, gxp, jgx, n_g, n, xi, mask, part, fin);
     SYMODE_LAUNCH_CHECK();
-    return hipSuccess;
+    return launch_finalize(fin, part, 1, gx, NACC, st);
 }
 
 template <class Lib>
 hipError_t launch_vjp(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
                       float* grad_xi, double* ws, int gx, hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
-    vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, xi, mask, grad_x, ws);
+    double* part = ws + WS_HEADER_DOUBLES;
+    const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
+    vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, xi, mask, grad_x, part, fin);
     SYMODE_LAUNCH_CHECK();
-    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
-    SYMODE_LAUNCH_CHECK();
-    return hipSuccess;
+    return launch_finalize(fin, part, 1, gx, NACC, st);
 }
 
 template <class Lib>
@@ -1422,11 +1514,11 @@ hipError_t launch_jvp_vjp(const float* x, const float* v, const float* g_out, co
                           const float* mask, float* grad_x, float* grad_v, float* grad_xi, double* ws, int gx,
                           hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
-    jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, ws);
+    double* part = ws + WS_HEADER_DOUBLES;
+    const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
+    jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, part, fin);
     SYMODE_LAUNCH_CHECK();
-    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
-    SYMODE_LAUNCH_CHECK();
-    return hipSuccess;
+    return launch_finalize(fin, part, 1, gx, NACC, st);
 }
 
 template <class Lib>
@@ -1444,12 +1536,12 @@ hipError_t launch_euler_jvp_vjp(const float* x, const float* v, const float* g_x
                                 const float* xi, const float* mask, int n_steps, float dt, float* grad_x, float* grad_v,
                                 float* grad_xi, double* ws, int gx, hipStream_t st) {
     constexpr int NACC = 1 + Lib::D * Lib::P;
+    double* part = ws + WS_HEADER_DOUBLES;
+    const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
     euler_jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_x, g_t, n, xi, mask, n_steps, dt, grad_x,
-                                                                  grad_v, ws);
+                                                                  grad_v, part, fin);
     SYMODE_LAUNCH_CHECK();
-    finalize_kernel<0><<<dim3(1), dim3(BLOCK), 0, st>>>(ws, gx, NACC, mask, 0.0f, 1.0f, nullptr, grad_xi);
-    SYMODE_LAUNCH_CHECK();
-    return hipSuccess;
+    return launch_finalize(fin, part, 1, gx, NACC, st);
 }
 
 template <class Lib>

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "symode_error_string": (c_char_p, [c_int]),
     "symode_lib_size": (c_int, [c_int, c_int, c_int]),
     "symode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_long, c_long]),
+    "symode_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
     "symode_theta": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "symode_forward": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "symode_odeint": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
@@ -58,7 +59,7 @@ _SIGNATURES = {
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SymodeError(RuntimeError):
@@ -105,6 +106,15 @@ class HipEngine:
         return t.contiguous()
 
     @staticmethod
+    def _dev_or_pinned(t: torch.Tensor, name: str) -> torch.Tensor:
+        """fp32 device tensor, or a pinned host tensor (hipHostMalloc memory is mapped into the device's address space
+        at the same address): lets a latency-bound caller hand coefficients in and take [loss | grad] out of ONE launch
+        without copy nodes on either side."""
+        if isinstance(t, torch.Tensor) and not t.is_cuda and t.is_pinned() and t.dtype == torch.float32 and t.is_contiguous():
+            return t
+        return HipEngine._dev(t, name)
+
+    @staticmethod
     def _ptr(t):
         return None if t is None else c_void_p(t.data_ptr())
 
@@ -124,8 +134,15 @@ class HipEngine:
         key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)   # one scratch per (device, stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() * 8 < need:
-            ws = torch.empty(max(need // 8 + 1, 1024), dtype=torch.float64, device=device)
+            ws = self.new_workspace(dev, need)
             self._ws[key] = ws
+        return ws
+
+    def new_workspace(self, device, nbytes) -> torch.Tensor:
+        """A private scratch buffer, header initialised on the current stream (symode_workspace_init): for callers
+        that replay launches from a HIP graph or from several streams in turn and must not share the engine's."""
+        ws = torch.empty(max(nbytes // 8 + 1, 1024), dtype=torch.float64, device=device)
+        self._check(self.lib.symode_workspace_init(self._ptr(ws), ws.numel() * 8, self._stream(ws)), "symode_workspace_init")
         return ws
 
     # -- entry points ------------------------------------------------------------------
@@ -190,23 +207,29 @@ class HipEngine:
             raise SymodeError(f"mask has {mask.numel()} elements, expected {n_problems}x{d}x{p}")
         return p
 
-    def loss_grad(self, x, dx, xi, mask, order, flags=0, inv_count=None, out=None):
-        """x, dx: (S, N, d) or (N, d); xi, mask: (S, d, p) or (d, p).  Returns (loss (S,), grad (S, d, p))."""
+    def loss_grad(self, x, dx, xi, mask, order, flags=0, inv_count=None, out=None, ws=None):
+        """x, dx: (S, N, d) or (N, d); xi, mask: (S, d, p) or (d, p).  Returns (loss (S,), grad (S, d, p)).
+        ``xi`` and ``out`` may be pinned host tensors (zero-copy); ``ws`` a private workspace from new_workspace()."""
         x, dx = self._dev(x, "x"), self._dev(dx, "dx")
         if x.shape != dx.shape:
             raise SymodeError(f"x {tuple(x.shape)} and dx {tuple(dx.shape)} differ")
         batched = x.dim() == 3
         S = x.shape[0] if batched else 1
         n, d = x.shape[-2], x.shape[-1]
-        xi = self._dev(xi, "xi")
+        xi = self._dev_or_pinned(xi, "xi")
         mask = None if mask is None else self._dev(mask, "mask")
         p = self._check_coef(xi, mask, d, order, flags, S)
         if out is None:
             loss = torch.empty(S, dtype=torch.float32, device=x.device)
             grad = torch.empty(S, d, p, dtype=torch.float32, device=x.device)
         else:
-            loss, grad = out
-        ws = self.workspace(x.device, d, order, flags, S, n)
+            loss, grad = (self._dev_or_pinned(o, "out") for o in out)
+            if loss.numel() != S or grad.numel() != S * d * p:
+                raise SymodeError(f"out buffers hold {loss.numel()} / {grad.numel()} elements, expected {S} / {S * d * p}")
+        if ws is None:
+            ws = self.workspace(x.device, d, order, flags, S, n)
+        elif ws.numel() * 8 < self.lib.symode_workspace_bytes(d, order, flags, S, n):
+            raise SymodeError("private workspace too small for this call")
         inv = 1.0 / (n * d) if inv_count is None else float(inv_count)
         self._check(self.lib.symode_loss_grad(self._ptr(x), self._ptr(dx), S, n, d, order, flags, self._ptr(xi),
                                               self._ptr(mask), inv, self._ptr(loss), self._ptr(grad), self._ptr(ws),
@@ -263,18 +286,24 @@ class HipEngine:
                                                   self._ptr(ws), ws.numel() * 8, self._stream(z)), "symode_symreg_linear")
         return loss[0], grad
 
-    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0):
+    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0, out=None, ws=None):
         x, gx, jgx = self._dev(x, "x"), self._dev(gx, "gx"), self._dev(jgx, "jgx")
         n, d = x.shape[-2], x.shape[-1]
         n_g = gx.shape[0]
         if gx.shape != (n_g, n, d) or jgx.shape != (n_g, n, d, d):
             raise SymodeError(f"gx {tuple(gx.shape)} / jgx {tuple(jgx.shape)} do not match x {tuple(x.shape)}")
-        xi = self._dev(xi, "xi")
+        xi = self._dev_or_pinned(xi, "xi")
         mask = None if mask is None else self._dev(mask, "mask")
         p = self._check_coef(xi, mask, d, order, flags)
-        loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        grad = torch.empty(d, p, dtype=torch.float32, device=x.device)
-        ws = self.workspace(x.device, d, order, flags, 1, n)
+        if out is None:
+            loss = torch.empty(1, dtype=torch.float32, device=x.device)
+            grad = torch.empty(d, p, dtype=torch.float32, device=x.device)
+        else:
+            loss, grad = (self._dev_or_pinned(o, "out") for o in out)
+            if loss.numel() != 1 or grad.numel() != d * p:
+                raise SymodeError("out buffers do not match (1,) / (d, p)")
+        if ws is None:
+            ws = self.workspace(x.device, d, order, flags, 1, n)
         self._check(self.lib.symode_symreg_reversed(self._ptr(x), self._ptr(gx), self._ptr(jgx), n_g, n, d, order, flags,
                                                     self._ptr(xi), self._ptr(mask), self._ptr(loss), self._ptr(grad),
                                                     self._ptr(ws), ws.numel() * 8, self._stream(x)),

@@ -286,7 +286,7 @@ class _HostShadow:
     the reference's semantics.
     """
 
-    def __init__(self, regressor, x, dx, reversed_sym=None, numpy_vars=True, use_graph=True):
+    def __init__(self, regressor, x, dx, reversed_sym=None, numpy_vars=True, use_graph=True, zero_copy=True):
         self.reg, self.x, self.dx = regressor, x, dx
         self.params = [p.detach().cpu().clone().requires_grad_(True) for p in regressor.parameters()]
         # numpy mode: ONE flat float32 vector aliases every host parameter (torch views of the same memory)
@@ -311,25 +311,61 @@ class _HostShadow:
         n_terms = 2 if reversed_sym is not None else 1
         self.d_out = torch.empty(n_terms * self.n_out, device=dev)
         self.h_out = torch.empty(n_terms * self.n_out).pin_memory()
+        # private scratch: the closure's launches must not depend on which stream replays them
+        eng = regressor.engine
+        self.ws = None
+        if hasattr(eng, 'new_workspace'):
+            self.ws = eng.new_workspace(dev, eng.lib.symode_workspace_bytes(regressor.latent_dim, regressor.poly_order,
+                                                                            regressor.flags, 1, x.shape[-2]))
         self._graph = None
-        if use_graph:
+        # Zero-copy closure: the kernel reads Xi from and writes [loss | grad] to pinned host memory, so one closure is
+        # ONE launch + one stream sync (the last workgroup finalises inside the launch) -- no copy nodes, no graph.
+        # Checked once against the copy path; any failure or difference leaves the copy path (+ HIP graph) in place.
+        self.zero_copy = False
+        if zero_copy and self.ws is not None:
+            self.zero_copy = self._zero_copy_works()
+        if not self.zero_copy and use_graph:
             self._capture()
+
+    def _kw(self):
+        return {'ws': self.ws} if self.ws is not None else {}
+
+    def _launch_zero_copy(self):
+        reg, (d, p), n = self.reg, self.mask.shape, self.n_out
+        reg.engine.loss_grad(self.x, self.dx, self.h_xi, reg.mask, reg.poly_order, reg.flags,
+                             out=(self.h_out[:1], self.h_out[1:n].view(d, p)), **self._kw())
+        if self.reversed_sym is not None:
+            gx, jgx = self.reversed_sym
+            reg.engine.symreg_reversed(self.x, gx, jgx, self.h_xi, reg.mask, reg.poly_order, reg.flags,
+                                       out=(self.h_out[n:n + 1], self.h_out[n + 1:].view(d, p)), **self._kw())
+
+    def _zero_copy_works(self):
+        try:
+            self.h_xi.copy_(self.get_Xi().detach())
+            self._launch()
+            torch.cuda.synchronize(self.x.device)
+            want = self.h_out.clone()
+            self.h_out.fill_(float('nan'))
+            self._launch_zero_copy()
+            torch.cuda.synchronize(self.x.device)
+            return bool(torch.equal(want, self.h_out))
+        except Exception:                               # pragma: no cover - depends on the runtime
+            return False
 
     def _launch(self):
         """Upload coefficients, the fused kernels, download [loss | grad]: everything between the two host buffers."""
         reg, (d, p), n = self.reg, self.mask.shape, self.n_out
         self.d_xi.copy_(self.h_xi, non_blocking=True)
         reg.engine.loss_grad(self.x, self.dx, self.d_xi, reg.mask, reg.poly_order, reg.flags,
-                             out=(self.d_out[:1], self.d_out[1:n].view(d, p)))
+                             out=(self.d_out[:1], self.d_out[1:n].view(d, p)), **self._kw())
         if self.reversed_sym is not None:
             gx, jgx = self.reversed_sym
-            ls, gs = reg.engine.symreg_reversed(self.x, gx, jgx, self.d_xi, reg.mask, reg.poly_order, reg.flags)
-            self.d_out[n:n + 1].copy_(ls.reshape(1))
-            self.d_out[n + 1:].copy_(gs.reshape(-1))
+            reg.engine.symreg_reversed(self.x, gx, jgx, self.d_xi, reg.mask, reg.poly_order, reg.flags,
+                                       out=(self.d_out[n:n + 1], self.d_out[n + 1:].view(d, p)), **self._kw())
         self.h_out.copy_(self.d_out, non_blocking=True)
 
     def _capture(self):
-        """The closure's device work is launch-bound (two ~6 us kernels between two tiny copies): capture it once
+        """Copy path: the closure's device work is launch-bound (a ~6 us kernel between two tiny copies): capture it once
         in a HIP graph and replay it per closure.  Any failure leaves the eager path in place."""
         try:
             self.h_xi.copy_(self.get_Xi().detach())
@@ -337,7 +373,7 @@ class _HostShadow:
             side.wait_stream(torch.cuda.current_stream(self.x.device))
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._launch()                      # warm-up: workspace of the capture stream, lazy inits
+                    self._launch()                      # warm-up: lazy inits
             torch.cuda.current_stream(self.x.device).wait_stream(side)
             torch.cuda.synchronize(self.x.device)
             g = torch.cuda.CUDAGraph()
@@ -390,7 +426,9 @@ class _HostShadow:
         Xi = self.get_Xi()
         self.h_xi.copy_(Xi.detach())
         n = self.n_out
-        if self._graph is not None:
+        if self.zero_copy:
+            self._launch_zero_copy()
+        elif self._graph is not None:
             self._graph.replay()
         else:
             self._launch()
@@ -614,7 +652,7 @@ def train_SIGED_lbfgs(
             gx, jgx = precompute_symmreg_r(x, autoencoder, generator, scale=0.01)
             rev = (torch.stack(gx).contiguous(), torch.stack(jgx).contiguous())
         shadow = _HostShadow(regressor, x, dx, reversed_sym=rev, numpy_vars=kwargs.get('numpy_lbfgs', False),
-                             use_graph=kwargs.get('hip_graph', True))
+                             use_graph=kwargs.get('hip_graph', True), zero_copy=kwargs.get('zero_copy', True))
 
         def closure_np(flat):                                                          # numpy variables: (loss, flat gradient)
             with torch.no_grad():

@@ -384,3 +384,106 @@ def test_plain_c_caller_of_the_abi_runs(tmp_path):
     assert "10 terms" in out
     assert np.isclose(loss, np.mean((0.05 * b) ** 2) / 2, rtol=1e-4)              # only dx1 is off: residual 0.05 * x1, mean over n*d
     assert np.isclose(grad, 2 * np.mean(0.05 * b * b) / 2, rtol=1e-4)             # d loss / d Xi[1][x1 column]
+
+
+# ------------------------------------------------------------- one-launch finalisation (tickets)
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("S,n,d,order", [(1, 125000, 2, 5), (1, 999, 2, 3), (7, 4097, 2, 3), (1, 50000, 3, 2), (64, 20000, 2, 2),
+                                         (1, 1 << 22, 2, 3)])
+def test_fused_finalize_bit_identical_to_two_launches(eng, S, n, d, order):
+    """The last-workgroup-done epilogue adds the partial rows in the order finalize_kernel does: same bits;
+    repeated launches on the same workspace keep giving them (the tickets reset themselves)."""
+    torch.manual_seed(S + n)
+    x = (torch.randn(S, n, d) * 0.7).cuda()
+    dx = torch.randn(S, n, d).cuda()
+    p = eng.lib_size(d, order, 0)
+    xi = (torch.randn(S, d, p) * 0.3).cuda()
+    mask = (torch.rand(S, d, p) > 0.3).float().cuda()
+    with _env(SYMODE_FUSED_FINALIZE=0):
+        l0, g0 = eng.loss_grad(x, dx, xi, mask, order)
+    with _env(SYMODE_FUSED_FINALIZE=1):
+        for _ in range(3):
+            l1, g1 = eng.loss_grad(x, dx, xi, mask, order)
+            assert torch.equal(l0, l1) and torch.equal(g0, g1)
+    want_l, want_g = O.mse_loss_and_grad(x[0].cpu(), dx[0].cpu(), xi[0].cpu(), mask[0].cpu(), order)
+    assert np.isclose(l1[0].item(), want_l.item(), rtol=2e-5)
+    assert_close_scaled(g1[0].cpu(), want_g, 2e-5, "fused finalize grad")
+
+
+def test_fused_finalize_other_reductions(eng, golden):
+    """vjp / jvp_vjp / euler_jvp_vjp / symreg_linear / symreg_reversed share the epilogue."""
+    torch.manual_seed(3)
+    n, d, order = 30011, 2, 3
+    p = eng.lib_size(d, order, 0)
+    x, v, g = (torch.randn(n, d).cuda() * 0.5 for _ in range(3))
+    xi = (torch.randn(d, p) * 0.3).cuda()
+    L = torch.tensor([[[0.0, 1.0], [-1.0, 0.0]]]).cuda()
+    gx = x[None] + 0.01 * torch.randn(1, n, d).cuda()
+    jgx = torch.eye(d).cuda().expand(1, n, d, d).contiguous() + 0.01 * torch.randn(1, n, d, d).cuda()
+
+    def run():
+        return (eng.vjp(x, g, xi, None, order)[1], eng.jvp_vjp(x, v, g, g, xi, None, order)[2],
+                eng.euler_jvp_vjp(x, v, g, g, xi, None, order, 0, 5, 0.01)[2],
+                *eng.symreg_linear(x, xi, None, L, order), *eng.symreg_reversed(x, gx, jgx, xi, None, order))
+    with _env(SYMODE_FUSED_FINALIZE=0):
+        a = run()
+    with _env(SYMODE_FUSED_FINALIZE=1):
+        b = run()
+        c = run()
+    for u, w, z in zip(a, b, c):
+        assert torch.equal(u, w) and torch.equal(u, z)
+
+
+def test_uninitialised_workspace_gives_nan_not_stale_numbers(eng):
+    """A workspace that never saw symode_workspace_init must not produce plausible output."""
+    import ctypes
+    n, d, order = 5000, 2, 3
+    p = eng.lib_size(d, order, 0)
+    x, dx = torch.randn(n, d).cuda(), torch.randn(n, d).cuda()
+    xi = torch.randn(d, p).cuda()
+    need = eng.lib.symode_workspace_bytes(d, order, 0, 1, n)
+    ws = torch.full((need // 8 + 1,), 7.0, dtype=torch.float64).cuda()          # garbage header
+    loss, grad = torch.zeros(1).cuda(), torch.zeros(d, p).cuda()
+    vp = lambda a: ctypes.c_void_p(a.data_ptr())  # noqa: E731
+    with _env(SYMODE_FUSED_FINALIZE=1):
+        rc = eng.lib.symode_loss_grad(vp(x), vp(dx), 1, n, d, order, 0, vp(xi), None, 1.0 / (n * d), vp(loss), vp(grad), vp(ws),
+                                      ws.numel() * 8, None)
+        torch.cuda.synchronize()
+        assert rc == 0 and torch.isnan(loss).all() and torch.isnan(grad[0, 0])
+        assert eng.lib.symode_workspace_init(vp(ws), ws.numel() * 8, None) == 0
+        rc = eng.lib.symode_loss_grad(vp(x), vp(dx), 1, n, d, order, 0, vp(xi), None, 1.0 / (n * d), vp(loss), vp(grad), vp(ws),
+                                      ws.numel() * 8, None)
+        torch.cuda.synchronize()
+    want_l, want_g = O.mse_loss_and_grad(x.cpu(), dx.cpu(), xi.cpu(), torch.ones(d, p), order)
+    assert rc == 0 and np.isclose(loss.item(), want_l.item(), rtol=2e-5)
+    assert_close_scaled(grad.cpu(), want_g, 2e-5, "grad after init")
+
+
+def test_zero_copy_closure_matches_copy_path(eng):
+    """_HostShadow: Xi read from / [loss | grad] written to pinned host memory by ONE launch == the copy path."""
+    from symode_amd.sindy import SINDyRegression
+    from symode_amd.train import _HostShadow
+    torch.manual_seed(0)
+    x, dx = torch.randn(125000, 2).cuda(), torch.randn(125000, 2).cuda()
+    reg = SINDyRegression(2, 3, False, False, threshold=0.05, device="cuda:0")
+    sh = _HostShadow(reg, x, dx, numpy_vars=False, use_graph=False, zero_copy=True)
+    assert sh.zero_copy, "pinned host memory is not device-visible on this box?"
+    _, vals, grads = sh.evaluate()
+    sh2 = _HostShadow(reg, x, dx, numpy_vars=False, use_graph=True, zero_copy=False)
+    _, vals2, grads2 = sh2.evaluate()
+    assert torch.equal(vals[0], vals2[0]) and torch.equal(grads[0], grads2[0])
