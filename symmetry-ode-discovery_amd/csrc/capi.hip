@@ -23,11 +23,17 @@ const LibOps* find_ops(int d, int order, int flags) {
 
 inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p % a) != 0; }
 
-// Gram passes are MFMA-bound, not latency-bound: at most 256 workgroups per launch keep the number of
-// partials the single finalize block has to add small.
+// Gram passes are MFMA-bound, not latency-bound: a bounded number of workgroups per launch (default 1024 = 4 per CU:
+// one wave per SIMD cannot cover the LDS round trip between MFMAs; SYMODE_GRAM_GRID for tuning runs) keeps the
+// number of partials the single finalize block has to add small.
 inline int gram_grid(long n, long S) {
+    static const long total = [] {
+        const char* e = getenv("SYMODE_GRAM_GRID");
+        const long v = e ? atol(e) : 1024;
+        return v < 2 ? 2 : v;
+    }();
     const int g = grid_x_for(n, S, 1);
-    const long cap = S >= 256 ? 2 : 256 / S;
+    const long cap = S >= total / 2 ? 2 : total / S;
     return g > cap ? (int)cap : g;
 }
 
