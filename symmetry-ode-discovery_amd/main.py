@@ -104,6 +104,7 @@ def main(argv=None):
         # a higher polynomial order only appends columns: the truth table extends with zeros
         true_eq = np.concatenate([true_eq, np.zeros((true_eq.shape[0], n_terms - true_eq.shape[1]))], axis=1)
     coef, cf, mse, cf_all, mse_all = eval_sindy_regressor(regressor_eval, true_eq)
+    print(f'Near-threshold coefficients (| |coef| - thr | < 1e-4): {regressor_eval.near_threshold or "none"}')
     print(f'Correct form: {cf}')
     print(f'MSE: {np.where(cf, mse, 0.0)}')
     print(f'MSE (any): {mse}')

@@ -1,10 +1,10 @@
 """Seed sweep of an equation-discovery config in ONE process per GPU (the reference runs
 ``for i in {0..49}; do python main.py --seed $i --config ...; done``, run_scripts/*.sh).
 
-    python -m symode_amd.main_sweep --config dosc/sindy_lbfgs.cfg --seed 0 --n_seeds 50
-    python -m symode_amd.main_sweep --config selkov/sindy_lbfgs.cfg --n_seeds 64 --method stlsq
+    python -m symode_amd.main_sweep --config dosc/noise20_sindy.cfg --seed 0 --n_seeds 50
+    python -m symode_amd.main_sweep --config selkov/noise20_eq_sindy.cfg --n_seeds 64 --method stlsq
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m symode_amd.main_sweep \
-        --config selkov/sindy_lbfgs.cfg --n_seeds 64 --method stlsq          # BASELINE config 3: 8 x MI355X
+        --config selkov/noise20_eq_sindy.cfg --n_seeds 64 --method stlsq          # BASELINE config 3: 8 x MI355X
 
 Every seed gets its own initial coefficients and its own ``--lbfgs_subsample`` draw of the data set
 (main.py:36-38).  ``--method lbfgs`` (default): all seeds are optimised in lockstep by sweep.SeedSweepLBFGS on
@@ -107,12 +107,14 @@ def main(argv=None, engine=None, backend='nccl'):
             raise SystemExit('--method stlsq sweeps the unconstrained library (use --method lbfgs for EquivSINDy-c)')
         sw = SeedSweepSTLSQ(x_all, dx_all, args['poly_order'], args['include_sine'], args['include_exp'], n_seeds=n_seeds,
                             subsample=args['lbfgs_subsample'], seed0=args['seed'], group=group, engine=engine)
-        Xi, mask, passes = sw.solve(args['w_sindy_reg'], args['threshold'], max_iter=max(1, args['num_epochs']))
+        Xi, mask, passes = sw.solve(args['w_sindy_reg'], args['threshold'], max_iter=max(1, args['num_epochs']),
+                                    lstsq_driver=args.get('lstsq_driver'))
         if rank == 0:
             class _T:                                               # library flags for the truth-table padding
                 include_sine, include_exp = args['include_sine'], args['include_exp']
             _write_results(args, seeds, Xi.numpy(), mask.numpy().astype(bool), padded_truth(mask.shape[-1], _T))
             print(f'{n_seeds} seeds x {sw.n_points} points (over {world} rank(s)), STLSQ passes {int(passes.min())}-{int(passes.max())}')
+            print(f'near-threshold coefficients (| |coef| - thr | < 1e-4): {sw.near_threshold if sw.near_threshold else "none"}')
             return aggregate_results(args['save_dir'], min_seed=seeds[0], max_seed=seeds[-1] + 1)
         return None
 
@@ -150,7 +152,8 @@ def main(argv=None, engine=None, backend='nccl'):
     Xi, mask = out['Xi'].cpu().numpy(), out['mask'].cpu().numpy().astype(bool)
     _write_results(args, seeds, Xi, mask, padded_truth(mask.shape[-1], template))
     print(f'{n_seeds} seeds, epochs used {int(out["epochs"].min())}-{int(out["epochs"].max())}, '
-          f'finished {int(out["finished"].sum())}, NaN {int(out["nan"].sum())}')
+          f'finished {int(out["finished"].sum())}, NaN {int(out["nan"].sum())}, '
+          f'seeds with near-threshold coefficients {[seeds[i] for i in torch.nonzero(out["near_threshold"]).flatten().tolist()] or "none"}')
     return aggregate_results(args['save_dir'], min_seed=seeds[0], max_seed=seeds[-1] + 1)
 
 

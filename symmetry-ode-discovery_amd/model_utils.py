@@ -201,6 +201,22 @@ def _module_jvp(module, h, t, require_grad):
 _CONST_HALF = {}
 
 
+def _fingerprint(*modules):
+    """Cheap identity of the frozen halves a cached quantity was computed from: storage address and in-place version
+    of every parameter, buffer and plain-tensor attribute the stock modules read (generator masks).  load_state_dict,
+    an optimiser step or ``mask *= ...`` all bump a version; a re-created module changes the addresses."""
+    out = []
+    for m in modules:
+        tensors = list(m.parameters()) + list(m.buffers())
+        tensors += [t for t in getattr(m, 'masks', []) if isinstance(t, torch.Tensor)]
+        out.append(tuple((t.data_ptr(), t._version) for t in tensors))
+    return tuple(out)
+
+
+def _zmean_key(z_mean):
+    return None if z_mean is None else (id(z_mean), z_mean._version)
+
+
 def _diag_block(mat, n_comps):
     """the common diagonal block of a block-diagonal (n_comps k, n_comps k) matrix, or None"""
     k = mat.shape[-1] // n_comps
@@ -226,11 +242,13 @@ def _by_rows(module_call, a, n_comps):
     return module_call(a.reshape(-1, n_comps, a.shape[-1])).reshape(a.shape[0], -1)
 
 
-def _const_half(kind, x_const, autoencoder, generator, blocks, zm, n_comps):
-    """cached per live batch tensor: (z_x, [decoder tangent | decoded g z_x per block])"""
-    key = (kind, x_const._version, id(autoencoder), id(generator), len(blocks))
+def _const_half(kind, x_const, autoencoder, generator, blocks, zm, n_comps, x_fx=None, z_mean=None):
+    """cached per live batch tensor, latent offset and state of the frozen modules: (z_x, [decoder tangent | decoded g z_x per block])"""
+    key = (kind, x_const._version, _fingerprint(autoencoder, generator), _zmean_key(z_mean), len(blocks))
     hit = _CONST_HALF.get(kind)
     if hit is None or hit[0]() is not x_const or hit[1] != key:
+        if x_fx is not None and not torch.equal(x_const, x_fx[:, 0]):       # checked when the half is (re)computed
+            raise ValueError('x_const must be the x component of x_fx (x_fx[:, 0])')
         with torch.no_grad():
             z0 = _by_rows(autoencoder.encode, x_const, n_comps) - zm
             outs = []
@@ -270,7 +288,7 @@ def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global
         if all(b is not None for b in blocks):
             with torch.set_grad_enabled(require_grad):
                 zm = _z_mean(autoencoder, z_mean)
-                _, v_xs = _const_half('i', x_const, autoencoder, generator, blocks, zm, nc)
+                _, v_xs = _const_half('i', x_const, autoencoder, generator, blocks, zm, nc, x_fx=x_fx, z_mean=z_mean)
                 x, fx = x_fx[:, 0], x_fx[:, 1]
                 z1 = _by_rows(autoencoder.encode, fx, nc) - zm
                 loss = 0.0
@@ -329,7 +347,7 @@ def symmreg_f(x_fx, autoencoder, generator, f, normalize='global', z_mean=None, 
         if all(b is not None for b in blocks):
             with torch.set_grad_enabled(require_grad):
                 zm = _z_mean(autoencoder, z_mean)
-                _, g_xs = _const_half('f', x_const, autoencoder, generator, blocks, zm, nc)
+                _, g_xs = _const_half('f', x_const, autoencoder, generator, blocks, zm, nc, x_fx=x_fx, z_mean=z_mean)
                 fx = x_fx[:, 1]
                 z1 = _by_rows(autoencoder.encode, fx, nc) - zm
                 loss = 0.0
@@ -454,7 +472,7 @@ def symmreg_r(x, autoencoder, generator, h, normalize='global', z_mean=None, req
     if isinstance(h, SINDyRegression) and normalize == 'global' and frozen and x.is_cuda:
         # identity of the LIVE tensor object + its version, not its address: the allocator hands the address of a freed
         # batch to the next one (every epoch draws a new subsample, main.py:36-38), a weak reference to it dies instead
-        key = (x._version, tuple(x.shape), id(autoencoder), id(generator), float(scale))
+        key = (x._version, tuple(x.shape), _fingerprint(autoencoder, generator), _zmean_key(z_mean), float(scale))
         hit = _R_CACHE.get('entry')
         if hit is None or hit[0]() is not x or hit[1] != key:
             gx, jgx = precompute_symmreg_r(x, autoencoder, generator, z_mean=z_mean, scale=scale)

@@ -44,6 +44,9 @@ _MAIN_ARGS = [
     ("st_freq", _I, 100), ("threshold", _F, 0.1), ("use_latent", _FLAG, None), ("distill_latent", _FLAG, None),
     ("eq_constraint", _FLAG, None), ("constrain_constant", _FLAG, None), ("int_t", _F, 0.1), ("int_dt", _F, 0.01),
     ("sindy_optimizer", _S, "adam"), ("lbfgs_subsample", _F, 1.0),
+    # least-squares driver of the STLSQ solves (new flag): gels = torch.linalg.lstsq on a GPU (default here),
+    # gelsy = its rank-truncating CPU default
+    ("lstsq_driver", _S, None),
     # PySR (accepted for config compatibility; that path is out of scope)
     ("pysr_subsample", _F, 1.0), ("pysr_bs", _I, 1000), ("pysr_symmreg", _FLAG, None),
     # run settings
@@ -61,7 +64,7 @@ _SINDY_ARGS = [
     ("learn_ae", _FLAG, None), ("ae_arch", _S, "mlp"), ("ortho_ae", _FLAG, None), ("batch_norm", _FLAG, None),
     ("load_ae", _FLAG, None), ("load_Lie", _FLAG, None), ("load_dir", _S, "autoencoder.pt"),
     ("poly_order", _I, 2), ("include_sine", _FLAG, None), ("include_exp", _FLAG, None), ("seq_thres_freq", _I, 100),
-    ("threshold", _F, 0.1),
+    ("threshold", _F, 0.1), ("lstsq_driver", _S, None),
     ("use_delay", _FLAG, None), ("delay_n", _I, 5), ("delay_q", _I, 3), ("delay_p", _I, 2),
     ("gpu", _I, 0), ("log_interval", _I, 1), ("save_interval", _I, 100), ("wandb_name", _S, "sindy-test"),
     ("save_dir", _S, "sindy-test"), ("seed", _I, 42),

@@ -2,7 +2,7 @@
 # Seeds 0-49 of one equation-discovery config (the reference's run_scripts/*.sh loop over `python main.py --seed $i`).
 #   L-BFGS SINDy / EquivSINDy-c configs run all seeds in ONE process on the batched kernels;
 #   configs with an autoencoder / symmetry regulariser fall back to the per-seed loop.
-# usage (from symmetry-ode-discovery_amd/):  bash run_scripts/sweep.sh dosc/sindy_lbfgs.cfg
+# usage (from symmetry-ode-discovery_amd/):  bash run_scripts/sweep.sh dosc/noise20_sindy.cfg
 set -e
 cfg=$1
 export PYTHONPATH=${PYTHONPATH:-..}

@@ -28,6 +28,19 @@ from .engine import get_engine, library_flags
 from .lstsq import lstsq_normal
 
 
+# BASELINE.md section 3 / SURVEY H5: masks come from the strict test |coef| > threshold after an iterative fit in fp32, so
+# a coefficient that lands within this band of the threshold could fall on the other side under a different (equally
+# valid) rounding.  Every thresholding event records such cases instead of hiding them; parity runs assert there are none.
+NEAR_THRESHOLD_BAND = 1e-4
+
+
+def near_threshold_cases(xi, mask, threshold, band=NEAR_THRESHOLD_BAND):
+    """[(row, col, |coef|)] for the still-active coefficients with | |coef| - threshold | < band (numpy in, list out)."""
+    a = np.abs(np.asarray(xi, dtype=np.float64))
+    hit = np.logical_and(np.abs(a - float(threshold)) < band, np.asarray(mask) > 0)
+    return [(int(i), int(k), float(a[i, k])) for i, k in zip(*np.nonzero(hit))]
+
+
 class _Forward(torch.autograd.Function):
     """dx_hat = Theta(x) (Xi*mask)^T, differentiable once w.r.t. x and Xi (HIP forward + vjp)."""
 
@@ -119,7 +132,8 @@ class SINDyRegression(nn.Module):
         poly_order: highest polynomial order (reference: max 3; here up to 5)
         include_sine / include_exp: append sin / exp columns (forced off under the constraint)
         L_list: list of Lie-algebra generators (d, d) -> equivariance constraint
-        kwargs: threshold, device, constrain_constant (required with L_list), lstsq_driver
+        kwargs: threshold, device, constrain_constant (required with L_list), lstsq_driver ('gels' | 'gelsy';
+                default: what torch.linalg.lstsq uses on that device -- gels on the GPU, gelsy on the CPU)
     """
 
     def __init__(self, latent_dim, poly_order, include_sine, include_exp, L_list=[], **kwargs):
@@ -131,8 +145,12 @@ class SINDyRegression(nn.Module):
         self.include_exp = include_exp and not self.constraint          # sindy.py:48
         self.L_list = L_list
         self.threshold = kwargs["threshold"]
-        self.lstsq_driver = kwargs.get("lstsq_driver", "gelsy")
         device = kwargs["device"]
+        # torch.linalg.lstsq's default driver depends on where the data lives: ?gels (full rank) on a GPU -- what the
+        # reference computes with its default --gpu 0 -- and the rank-truncating ?gelsy on the CPU (rcond = eps_fp32 *
+        # max(m, n) = 1.5e-2 at m = 125 010 rows: any library with cond > ~67 is solved rank-deficient there).  This
+        # engine is GPU-only, so 'gels' is the default on a HIP device; 'gelsy' reproduces the CPU-made golden vectors.
+        self.lstsq_driver = kwargs.get("lstsq_driver") or ("gels" if torch.device(device).type == "cuda" else "gelsy")
         self.engine = kwargs.get("engine") or get_engine()
         self.flags = library_flags(self.include_sine, self.include_exp)
         n_terms = self.engine.lib_size(latent_dim, poly_order, self.flags)   # raises if not compiled in
@@ -149,6 +167,7 @@ class SINDyRegression(nn.Module):
             self.Xi = nn.Parameter(torch.randn(self.latent_dim, n_terms, device=device))
         self.mask = torch.ones_like(self.Xi, device=device)
         self._gram_cache = None
+        self.near_threshold = []          # one dict per near-threshold coefficient met at a thresholding event
 
     # ------------------------------------------------------------------ evaluation
     def _coef(self):
@@ -214,8 +233,13 @@ class SINDyRegression(nn.Module):
         return library.term_count(self.latent_dim, self.poly_order, self.include_sine, self.include_exp)
 
     # ------------------------------------------------------------------ sparsity
+    def note_near_threshold(self, xi, mask, threshold, where=''):
+        for i, k, v in near_threshold_cases(xi, mask, threshold):
+            self.near_threshold.append({'where': where, 'threshold': float(threshold), 'index': (i, k), 'abs_coef': v})
+
     def set_threshold(self, threshold):                                   # sindy.py:192-194 (strict >)
         self.Xi = self.get_Xi() if self.constraint else self.Xi
+        self.note_near_threshold(self.Xi.detach().cpu().numpy(), self.mask.cpu().numpy(), threshold, 'set_threshold')
         self.mask.data = torch.logical_and(torch.abs(self.Xi) > threshold, self.mask).float()
 
     def reset_mask(self):                                                 # sindy.py:197-198
@@ -358,6 +382,7 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
     else:
         # the solution was just made on the host: threshold it there (same fp32 values, same strict >, sindy.py:192-194)
         # and upload the mask -- instead of three device launches and a synchronising allclose
+        regressor.note_near_threshold(xi_host, mask, st_threshold, 'solve_SINDy_one_step')
         new_mask = np.logical_and(np.abs(xi_host) > np.float32(st_threshold), mask)
         regressor.mask.data = torch.from_numpy(new_mask.astype(np.float32)).to(dev)
         converged = bool(np.array_equal(new_mask, mask))

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from .engine import get_engine, library_flags
-from .sindy import stlsq_solve_from_gram
+from .sindy import NEAR_THRESHOLD_BAND, near_threshold_cases, stlsq_solve_from_gram
 
 
 class SeedSweepSTLSQ:
@@ -51,18 +51,22 @@ class SeedSweepSTLSQ:
             self._gram, self.n_points = G.cpu().numpy(), int(n.item())
         return self._gram
 
-    def solve(self, w_sindy_reg, threshold, max_iter=10, lstsq_driver="gelsy"):
+    def solve(self, w_sindy_reg, threshold, max_iter=10, lstsq_driver=None):
         """STLSQ to convergence for every seed (train.py:872-887 per seed).
         Returns (Xi (S, d, p) float32, mask (S, d, p) float32, passes (S,))."""
         G = self.grams()
+        if lstsq_driver is None:                   # torch.linalg.lstsq's default on the device the data lives on (sindy.py)
+            lstsq_driver = "gels" if self.x.is_cuda else "gelsy"
         S, d, p = self.S, self.d, self.p
         Xi = np.zeros((S, d, p), dtype=np.float32)
         mask = np.ones((S, d, p), dtype=bool)
         passes = np.zeros(S, dtype=np.int64)
+        self.near_threshold = []              # (seed index, pass, row, col, |coef|): BASELINE.md section 3
         for s in range(S):
             for it in range(max_iter):
                 xi, _ = stlsq_solve_from_gram(G[s], self.n_points, mask[s], float(w_sindy_reg), d, lstsq_driver)
                 xi32 = xi.astype(np.float32)
+                self.near_threshold += [(s, it, i, k, v) for i, k, v in near_threshold_cases(xi32, mask[s], threshold)]
                 new_mask = np.logical_and(np.abs(xi32) > np.float32(threshold), mask[s])   # strict >, monotone (sindy.py:194)
                 converged = np.array_equal(new_mask, mask[s])
                 Xi[s], mask[s], passes[s] = xi32, new_mask, it + 1
@@ -253,6 +257,7 @@ class SeedSweepLBFGS:
         done = torch.zeros(S, dtype=torch.bool, device=P.device)
         nan = torch.zeros(S, dtype=torch.bool, device=P.device)
         epochs = torch.zeros(S, dtype=torch.long, device=P.device)
+        near = torch.zeros(S, dtype=torch.long, device=P.device)         # near-threshold coefficients met per seed
         for epoch in range(num_epochs):
             if epoch % 4 == 0 and bool(done.all()):                        # host sync every 4th epoch only
                 break
@@ -273,9 +278,12 @@ class SeedSweepLBFGS:
             ev = thr_conv | thr_freq
             Xi = self._xi(P)
             new_mask = torch.logical_and(Xi.abs() > self.threshold, self.mask > 0).float()
+            close = ((Xi.abs() - self.threshold).abs() < NEAR_THRESHOLD_BAND) & (self.mask > 0)
+            near = near + torch.where(ev, close.sum(dim=(1, 2)), torch.zeros_like(near))
             self.mask = torch.where(ev[:, None, None], new_mask, self.mask)   # strict >, monotone (sindy.py:194)
             opt.reset(ev)
             n_iters = torch.where(ev, torch.zeros_like(n_iters), n_iters)
             pprev = torch.where(thr_conv[:, None], P, pprev)               # only on convergence-triggered events (:718)
             prev = torch.where((live & ~final)[:, None], P, prev)
-        return {"Xi": self._xi(P), "mask": self.mask, "params": P, "epochs": epochs, "finished": done & ~nan, "nan": nan}
+        return {"Xi": self._xi(P), "mask": self.mask, "params": P, "epochs": epochs, "finished": done & ~nan, "nan": nan,
+                "near_threshold": near}

@@ -401,7 +401,9 @@ class _HostShadow:
 
     def set_threshold(self, threshold):                                                 # sindy.py:192-194
         with torch.no_grad():
-            self.mask = torch.logical_and(torch.abs(self.get_Xi()) > threshold, self.mask).float()
+            Xi = self.get_Xi()
+            self.reg.note_near_threshold(Xi.numpy(), self.mask.numpy(), threshold, 'set_threshold (host L-BFGS variables)')
+            self.mask = torch.logical_and(torch.abs(Xi) > threshold, self.mask).float()
         self.sync()
 
     def sync(self):
@@ -811,7 +813,8 @@ def train_WSINDy(wrapper, train_x, num_epochs, device, log_interval, save_interv
     """train.py:855-869"""
     train_x = train_x.to(device)
     for epoch in range(num_epochs):
-        residual, completed = wrapper.solve(train_x, w_sindy_reg, threshold)
+        residual, completed = wrapper.solve(train_x, w_sindy_reg, threshold,
+                                            **({'lstsq_driver': kwargs['lstsq_driver']} if kwargs.get('lstsq_driver') else {}))
         if (epoch + 1) % log_interval == 0:
             print(f'Iteration {epoch}, loss: {residual:.4f}')
             wrapper.regressor.print()
@@ -825,7 +828,8 @@ def train_SINDy(regressor, x, dx, num_epochs, device, log_interval, save_interva
     """Sequential-threshold least squares until the support stops changing   (train.py:872-887)."""
     x, dx = x.to(device), dx.to(device)
     for epoch in range(num_epochs):
-        residual, completed = solve_SINDy_one_step(regressor, x, dx, w_sindy_reg, threshold)
+        residual, completed = solve_SINDy_one_step(regressor, x, dx, w_sindy_reg, threshold,
+                                                   **({'lstsq_driver': kwargs['lstsq_driver']} if kwargs.get('lstsq_driver') else {}))
         if (epoch + 1) % log_interval == 0:
             print(f'Iteration {epoch}, loss: {residual:.4f}')
             regressor.print()

@@ -35,7 +35,7 @@ def main():
     D.RD_SYNTH.update(n=a.grid, n_samples=a.n_samples)
     torch.manual_seed(0)
     np.random.seed(0)
-    cfg = os.path.join(os.path.dirname(symode_amd.__file__), "run_configs", "rd", "latent_sindy_equiv.cfg")
+    cfg = os.path.join(os.path.dirname(symode_amd.__file__), "run_configs", "rd", "sym_eq.cfg")
     argv = parser_utils.parse_config(cfg) + ["--num_epochs", str(a.epochs), "--log_interval", "1000", "--save_interval", "1000"]
     args = vars(parser_utils.get_args(argv=argv))
     args["device"] = dev

@@ -74,7 +74,7 @@ def test_config3_selkov_64_seed_sweep_full_size(S):
     x, dx = S.data.make_dataset("selkov", 10, 10000, dt=0.002, noise=0.0, seed=2, device=DEV)
     x, dx = x[0], dx[0]
     sw = S.sweep.SeedSweepSTLSQ(x, dx, 3, n_seeds=64, subsample=0.5, seed0=0)
-    Xi, mask, passes = sw.solve(0.0, 0.075)
+    Xi, mask, passes = sw.solve(0.0, 0.075, lstsq_driver="gelsy")          # the oracle below is the CPU reference path
     assert sw.idx.shape == (64, 50000)
     xc, dxc = x.cpu(), dx.cpu()
     for s in (0, 31, 63):
@@ -171,7 +171,7 @@ def test_config4_reaction_diffusion_latent_sindy_train_lassi(S, tmp_path, monkey
     xb, dxb = xb.to(DEV), dxb.to(DEV)
     z = ae.encode(xb)[:, 0].detach().contiguous().requires_grad_(True)
     dz = ae.compute_dz(xb, dxb)[:, 0].contiguous()
-    r2 = S.SINDyRegression(2, 2, False, False, threshold=0.02, device=DEV)
+    r2 = S.SINDyRegression(2, 2, False, False, threshold=0.02, device=DEV, lstsq_driver="gelsy")
     res = S.sindy.solve_SINDy(r2, z, dz, 0.1, 0.02)
     (gz,) = torch.autograd.grad(res, z)
     zc, dzc = z.detach().cpu(), dz.detach().cpu()

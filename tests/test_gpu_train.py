@@ -127,13 +127,13 @@ def test_forward_and_jvp_gradients_vs_fp64_double_backward(S):
 def test_train_sindy_and_wsindy_on_gpu(S, golden):
     g = golden("f3_stlsq")
     x, dx = t(g["selkov_ridge_x"]), t(g["selkov_ridge_dx"])
-    r = S.SINDyRegression(2, 3, False, False, threshold=0.075, device=DEV)
+    r = S.SINDyRegression(2, 3, False, False, threshold=0.075, device=DEV, lstsq_driver="gelsy")   # CPU-made goldens
     S.train.train_SINDy(r, x, dx, num_epochs=8, device=DEV, log_interval=100, save_interval=100, save_dir="t", w_sindy_reg=0.1, threshold=0.075)
     assert np.array_equal(r.mask.cpu().numpy(), g["selkov_ridge_masks"][-1])
     w = golden("f7_wsindy")
     xw = t(w["x"]).to(DEV)
     n = xw.shape[0]
-    r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV)
+    r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV, lstsq_driver="gelsy")
     wr = S.WSINDyWrapper(r, torch.arange(n) * 0.02, float(w["tmax"]), device=DEV)
     assert np.allclose(wr.V[:, :48].cpu().numpy(), w["V_head"], rtol=1e-5, atol=1e-7)
     assert np.allclose(wr.V_drv[:, :48].cpu().numpy(), w["V_drv_head"], rtol=1e-5, atol=1e-7)

@@ -23,7 +23,8 @@ def test_parser_defaults_and_flag_names():
     assert (a.sindy_optimizer, a.lbfgs_subsample, a.sym_reg_type, a.w_sym_reg, a.int_t, a.int_dt) == ("adam", 1.0, "i", 0.0, 0.1, 0.01)
     assert (a.repr, a.group_idx, a.ae_arch, a.hidden_dim, a.n_layers, a.seed, a.gpu) == ("(1,so2)", "0", "mlp", 512, 5, 42, 0)
     assert a.eq_constraint is False and a.activation_args == [] and str(a.device) in ("cpu", "cuda:0")
-    assert len(parser_utils._MAIN_ARGS) == 76       # + --config, --help = the reference parser's 78 actions
+    assert len(parser_utils._MAIN_ARGS) == 77       # the reference parser's 76 flags (+ --config, --help = its 78 actions) + --lstsq_driver
+    assert a.lstsq_driver is None                   # = torch.linalg.lstsq's default on the device the data lives on
     s = parser_utils.get_sindy_args(argv=[])
     assert (s.lr, s.reg_type, s.w_reg, s.seq_thres_freq, s.batch_size, s.save_dir) == (1e-3, "l1", 0.1, 100, 64, "sindy-test")
 
@@ -202,3 +203,78 @@ def test_mlp_split_autoencoder_layout():
     x2 = x.clone()
     x2[..., 6:] += 1.0                                           # the second half only reaches the second model
     assert torch.equal(ae.encode(x2)[..., :2], z[..., :2]) and not torch.equal(ae.encode(x2)[..., 2:], z[..., 2:])
+
+
+def test_reference_config_names_parse(monkeypatch):
+    """Every config / script name a user of the reference types exists here and parses -- through the reference's
+    ``--config`` rules (parser_utils.py:100-118, 183-186) -- to the effective settings of SURVEY.md Appendix A."""
+    import importlib.util
+    import os
+    import symode_amd
+    from symode_amd import parser_utils
+    pkg = os.path.dirname(os.path.abspath(symode_amd.__file__))
+    spec = importlib.util.spec_from_file_location("write_run_configs", os.path.join(os.path.dirname(pkg), "tools", "write_run_configs.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    monkeypatch.chdir(pkg)                                     # the package directory holds run_configs/
+    defaults = vars(parser_utils.get_args(construct_parser=True).parse_args([]))
+    for rel, row in W.CONFIGS.items():
+        assert os.path.exists(os.path.join("run_configs", rel)), rel
+        got = vars(parser_utils.get_args(argv=["--config", rel]))
+        for key, value in row.items():
+            assert got[key] == value, (rel, key, got[key], value)
+        for key, value in defaults.items():                    # everything the row does not set stays at the parser default
+            if key not in row and key != "config":
+                assert got[key] == value, (rel, key)
+    for name, (module, cfg) in W.SCRIPTS.items():
+        text = open(os.path.join("run_scripts", name + ".sh")).read()
+        assert f"--config {cfg}" in text and f"symode_amd.{module}" in text and "{0..49}" in text
+    # Appendix A, spelled out for the five BASELINE configurations
+    a = vars(parser_utils.get_args(argv=["--config", "dosc/noise20_sindy.cfg", "--seed", "7"]))
+    assert (a["task"], a["noise"], a["smoothing"], a["sindy_optimizer"], a["lbfgs_subsample"], a["lr_sindy"], a["poly_order"],
+            a["st_freq"], a["threshold"], a["num_epochs"], a["seed"]) == ("dosc", 0.2, "gp", "lbfgs", 0.5, 0.1, 2, 50, 5e-2, 200, 7)
+    a = vars(parser_utils.get_args(argv=["--config", "dosc/noise20_esindy.cfg"]))
+    assert a["eq_constraint"] and a["repr"] == "(1,so2)" and a["ae_arch"] == "none" and (a["lr_sindy"], a["st_freq"], a["threshold"]) == (1.0, 100, 1e-2)
+    a = vars(parser_utils.get_args(argv=["--config", "lv/noise99_eq_isymreg.cfg"]))
+    assert a["sym_reg_type"] == "i" and a["include_exp"] and a["poly_order"] == 2 and a["fix_laligan"] and a["load_laligan"] == "laligan-noise99-lv"
+    assert (a["lbfgs_subsample"], a["w_sym_reg"], a["threshold"], a["int_t"], a["int_dt"], a["n_comps"], a["repr"]) == (0.01, 0.1, 0.15, 0.1, 0.01, 2, "(2,1,2)")
+    a = vars(parser_utils.get_args(argv=["--config", "selkov/noise20_eq_sindy.cfg"]))
+    assert (a["poly_order"], a["lr_sindy"], a["st_freq"], a["threshold"], a["lbfgs_subsample"], a["num_epochs"]) == (3, 1.0, 50, 7.5e-2, 0.5, 200)
+    a = vars(parser_utils.get_args(argv=["--config", "rd/sym_eq.cfg"]))
+    assert a["task"] == "mt_rd" and a["include_sindy"] and a["eq_constraint"] and a["constrain_constant"] and a["w_sindy_x"] == 0.0
+    assert (a["w_sindy_z"], a["batch_size"], a["lr_ae"], a["gan_st_thres"], a["latent_dim"], a["threshold"], a["w_sindy_reg"]) == (0.1, 64, 3e-4, 0.05, 2, 0.1, 0.1)
+
+
+def test_symmetry_caches_see_parameter_and_offset_changes():
+    """The Xi-independent halves are cached per live batch; a changed latent offset, a load_state_dict or an in-place
+    update of the frozen autoencoder / generator must invalidate them, and a wrong x_const must raise."""
+    import torch
+    import pytest
+    from symode_amd import model_utils as MU
+    from symode_amd.autoencoder import AutoEncoder
+    from symode_amd.lie import LieGenerator
+    torch.manual_seed(0)
+    ae = AutoEncoder(ae_arch="mlp", input_dim=2, hidden_dim=8, latent_dim=2, n_layers=2, n_comps=2, activation="Tanh",
+                     activation_args=[], batch_norm=True, ortho_ae=False).eval()    # the latent offset is the last BatchNorm's bias
+    gen = LieGenerator(repr="(2,sim2)", group_idx="0").eval()
+    for p in list(ae.parameters()) + list(gen.parameters()):
+        p.requires_grad = False
+    x = torch.randn(32, 2)
+    f = lambda a: a + 0.1 * torch.tanh(a)  # noqa: E731
+    x_fx = torch.stack([x, f(x)], dim=1)
+
+    def both(z_mean=None):
+        a = MU.symmreg_f(x_fx, ae, gen, f, z_mean=z_mean, x_const=x)
+        b = MU.symmreg_f(x_fx, ae, gen, f, z_mean=z_mean)
+        return a.item(), b.item()
+    a, b = both()
+    assert abs(a - b) <= 1e-5 * abs(b)
+    zm = torch.full((2,), 0.3)
+    a, b = both(zm)                                             # same batch, new latent offset
+    assert abs(a - b) <= 1e-5 * abs(b)
+    with torch.no_grad():
+        ae.decoder[0].weight.mul_(1.5)                          # in-place update of a "frozen" module
+    a, b = both(zm)
+    assert abs(a - b) <= 1e-5 * abs(b)
+    with pytest.raises(ValueError):
+        MU.symmreg_f(x_fx, ae, gen, f, x_const=x + 1.0)
