@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark: trajectory-points/s through the fused Theta-build + residual (+ gradient) pass.
+"""Headline benchmark: trajectory-points/s through Theta-build + residual (+ gradient) + symmetry regulariser.
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): damped oscillator, n_ics=50 x steps=2500 x dim=2 fp32,
-poly-order 5 (p = 21), EquivSINDy-c (so2 equivariance constraint, Xi = reshape(Q beta) + const),
-batched over S independent (trajectory, seed) problems per GPU that are resident in HBM.
-One *step* = one closure evaluation of every problem: Xi from (beta, const), the fused HIP
-kernel (loss + dloss/dXi, Theta never materialised), projection of the gradient onto
-(beta, const) and -- for N > 1 -- the RCCL all-reduce of the packed [loss | grad] partials
-(every rank holds its own shard of each problem's trajectories: weak scaling).
+Workload (BASELINE.json configs[1]): damped oscillator, n_ics=50 x steps=2500 x dim=2 fp32, poly-order 5 (p = 21),
+EquivSINDy-c (so2 equivariance constraint, Xi = reshape(Q beta) + const), batched over S independent
+(trajectory, seed) problems per GPU that are resident in HBM.  One *step* = one closure evaluation of every problem:
+Xi from (beta, const); the fused Theta + residual + loss + dloss/dXi kernel (Theta never materialised); the fused
+Lie-symmetry regulariser on precomputed (g(x), J_g(x)) -- reversed form, model_utils.py:126-170 -- with its gradient;
+projection of the summed gradient onto (beta, const); and -- for N > 1 -- the RCCL all-reduce of the packed
+[loss | grad] partials (every rank holds its own shard of each problem's trajectories: weak scaling).
+
+``--gpus N`` without a torchrun environment starts the N ranks itself (``python -m torch.distributed.run``) BEFORE
+anything touches the GPU and relays rank 0's line.
 
 Prints ONE JSON line (rank 0) following the driver's contract, plus
-  roofline     : the dominant kernel priced against the HBM roof (algorithmic bytes / live
-                 HIP-event time; PMC traffic when profiles/pmc_traffic.json is present),
-  cpu_baseline : the CPU oracle ("port" of the reference op sequence) timed on the host cores
-                 on a bounded sample of the same workload (rank 0, N = 1 only).
+  roofline      : the dominant kernel of the step priced against the HBM roof (algorithmic bytes / live HIP-event time;
+                  PMC traffic when profiles/pmc_traffic.json holds it),
+  roofline_legs : the same for every kernel of the step and for the Euler-flow pair of the infinitesimal regulariser
+                  (timed after the K steps on a slice of the resident points; not part of ``value``),
+  cpu_baseline  : the CPU oracle ("port" of the reference op sequence) timed on the host cores on a bounded sample of
+                  the same step (rank 0, N = 1 only),
+  single_problem: the bare 50x2500x2 shape, kernel time and closure wall time.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,10 +34,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4      # lane-instructions / ns: 256 CUs x 4 SIMD-32 x 2.4 GHz (fp32 FMA = 2 flop each)
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--problems", type=int, default=8192, help="(trajectory, seed) problems per GPU")
+    ap.add_argument("--n_ics", type=int, default=50)
+    ap.add_argument("--n_steps", type=int, default=2500)
+    ap.add_argument("--poly_order", type=int, default=5)
+    ap.add_argument("--sym_reg", choices=["r", "none"], default="r",
+                    help="'r': the step includes the fused reversed symmetry regulariser (default); 'none': Theta + residual only")
+    ap.add_argument("--w_sym_reg", type=float, default=0.1)
+    ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernels (default: 1 on one GPU, 2 when the [loss|grad] buffer is all-reduced)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_seconds", type=float, default=12.0)
+    ap.add_argument("--shard", choices=["points", "seeds"], default="points",
+                    help="N > 1: 'points' = every rank holds a shard of each problem's trajectories and the packed "
+                         "[loss|grad] partials are all-reduced (RCCL, default); 'seeds' = every rank owns whole problems, "
+                         "no data-path collective")
+    ap.add_argument("--rehearse_gloo", action="store_true",
+                    help="N > 1 rehearsal on a ONE-GPU box: every rank uses cuda:0 and the collectives go through gloo "
+                         "(exercises the sharded code path; the number it prints is not a scaling measurement)")
+    ap.add_argument("--force_dist", action="store_true",
+                    help="initialise the RCCL process group and run the collective path even with one rank (self-test)")
+    ap.add_argument("--profile", action="store_true",
+                    help="profiling run: only the batched steps (no legs, no single-problem loop, no CPU baseline), so that "
+                         "rocprofv3 --stats averages the step's launches alone")
+    ap.add_argument("--master_port", type=int, default=29517)
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(a):
+    """``python bench.py --gpus N`` with no torchrun environment: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and relay rank 0's JSON line.  This process never touches the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(a.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.exit(proc.returncode if proc.returncode != 0 or line is not None else 1)
 
 
 class _StdoutToStderr:
@@ -49,76 +103,121 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--problems", type=int, default=8192, help="(trajectory, seed) problems per GPU")
-    ap.add_argument("--n_ics", type=int, default=50)
-    ap.add_argument("--n_steps", type=int, default=2500)
-    ap.add_argument("--poly_order", type=int, default=5)
-    ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernel (default: 1 on one GPU, 2 when the [loss|grad] buffer is all-reduced)")
-    ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_seconds", type=float, default=12.0)
-    ap.add_argument("--shard", choices=["points", "seeds"], default="points",
-                    help="N > 1: 'points' = every rank holds a shard of each problem's trajectories and the packed "
-                         "[loss|grad] partials are all-reduced (RCCL, default); 'seeds' = every rank owns whole problems, "
-                         "no data-path collective")
-    ap.add_argument("--rehearse_gloo", action="store_true",
-                    help="N > 1 rehearsal on a ONE-GPU box: every rank uses cuda:0 and the collectives go through gloo "
-                         "(exercises the sharded code path; the number it prints is not a scaling measurement)")
-    ap.add_argument("--force_dist", action="store_true",
-                    help="initialise the RCCL process group and run the collective path even with one rank (self-test)")
-    ap.add_argument("--profile", action="store_true",
-                    help="profiling run: only the batched steps (no single-problem loop, no CPU baseline), so that "
-                         "rocprofv3 --stats averages the headline launches alone")
-    return ap.parse_args()
-
-
-def cpu_baseline(x_s, dx_s, Xi_s, order, seconds):
-    """Oracle closure body (Theta cat-of-products, matmul, MSE, autograd backward) on host cores."""
+def cpu_baseline(x_s, dx_s, Xi_s, order, seconds, sym=None):
+    """Oracle closure body (Theta cat-of-products, matmul, MSE [+ the reversed regulariser on the same precomputed
+    (g(x), J_g)], autograd backward) on the host cores, one problem after the other."""
+    import torch
     from oracle import sindy_oracle as O
-    mask = torch.ones_like(Xi_s[0])
     n_prob, n_pts = x_s.shape[0], x_s.shape[1]
     # the box exposes every host core but a 1-GPU job owns a 16-core share: more threads only thrash
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(16, avail)))
+    regs = [O.OracleRegressor(2, order, Xi0=Xi_s[s].clone()) for s in range(n_prob)]
+
+    def closure(s):
+        reg = regs[s]
+        reg.Xi.grad = None
+        loss = torch.nn.functional.mse_loss(reg(x_s[s]), dx_s[s])
+        if sym is not None:
+            gx, jgx, w = sym
+            loss = loss + w * O.symreg_reversed_precomputed(x_s[s], list(gx[s]), list(jgx[s]), reg)
+        loss.backward()
+
     for s in range(min(2, n_prob)):
-        O.mse_loss_and_grad(x_s[s], dx_s[s], Xi_s[s], mask, order)
+        closure(s)
     t0, calls = time.perf_counter(), 0
     while time.perf_counter() - t0 < seconds:
-        s = calls % n_prob
-        O.mse_loss_and_grad(x_s[s], dx_s[s], Xi_s[s], mask, order)
+        closure(calls % n_prob)
         calls += 1
     dt = time.perf_counter() - t0
+    what = "Theta-build + residual + reversed sym-reg + backward" if sym is not None else "Theta-build + residual + backward"
     return {"value": calls * n_pts / dt, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{calls} closure evaluations (Theta-build + residual + backward) over {n_prob} of the "
-                      f"problems, {n_pts} points each, {dt:.1f} s of CPU work, torch {torch.__version__} CPU fp32"}
+            "sample": f"{calls} closure evaluations ({what}) over {n_prob} of the problems, {n_pts} points each, "
+                      f"{dt:.1f} s of CPU work, torch {torch.__version__} CPU fp32"}
+
+
+class _KernelTimer:
+    """HIP events around every call of one engine method (on torch's current stream, where the kernels are launched)."""
+
+    def __init__(self, eng, name):
+        import torch
+        self.torch, self.eng, self.name, self.orig, self.events = torch, eng, name, getattr(eng, name), []
+
+    def __enter__(self):
+        def timed(*args, **kw):
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(*args, **kw)
+            e1.record()
+            self.events.append((e0, e1))
+            return out
+        setattr(self.eng, self.name, timed)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.eng, self.name, self.orig)
+
+    def ms(self):
+        return sorted(e0.elapsed_time(e1) for e0, e1 in self.events)
+
+
+def _leg(kernel, bytes_per_launch, ms_sorted, traffic=None, **extra):
+    if not ms_sorted:
+        return None
+    avg = sum(ms_sorted) / len(ms_sorted)
+    ach = bytes_per_launch / (avg * 1e-3) / 1e9
+    leg = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": traffic, "kernel_ms": avg, "kernel_ms_min": ms_sorted[0], "kernel_ms_median": ms_sorted[len(ms_sorted) // 2],
+           "kernel_ms_max": ms_sorted[-1], "bytes_per_launch": bytes_per_launch, "launches": len(ms_sorted)}
+    leg.update(extra)
+    return leg
+
+
+def _pmc_traffic(kernel_key, points_per_launch):
+    """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate
+    passes, gfx950 correction), scaled per point when it was taken on another launch size (streaming kernels)."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(pmc))
+        rec = rec.get("kernels", {}).get(kernel_key) or (rec if kernel_key == "loss_grad" and "loss_grad_bytes_per_point" in rec else None)
+        if rec is None:
+            return None
+        per_point = rec.get("bytes_per_point", rec.get("loss_grad_bytes_per_point"))
+        return None if per_point is None else per_point * points_per_launch
+    except Exception:
+        return None
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)                                   # never returns
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop the torchrun environment "
+                         f"and let bench.py start them)")
     if a.rehearse_gloo:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or a.force_dist
+    ranks_observed = 1
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.master_port), RANK="0", WORLD_SIZE="1")
         with _StdoutToStderr():
             if a.rehearse_gloo:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=dev)
-            warm = torch.zeros(1, device=dev)
+            warm = torch.ones(1, device=dev)
             dist.all_reduce(warm)                      # creates the RCCL communicator (banner goes to stderr)
             torch.cuda.synchronize()
+        ranks_observed = int(round(warm.item()))       # what the collective itself counted
 
     import symode_amd
     from symode_amd import data
@@ -134,9 +233,18 @@ def main():
     so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
     Q, use_kron = constraint_Q([so2], d, order)
     Q = Q.to(dev)
+    sym = None
+    if a.sym_reg == "r":
+        # (g(x), J_g(x)) of ONE group element exp(0.01 * so2) -- what precompute_symmreg_r leaves resident for a frozen
+        # autoencoder (model_utils.py:172-211); here the decoder/encoder pair is the identity, so g is the rotation itself
+        R = torch.matrix_exp(0.01 * so2).to(dev)
+        gx = (x @ R.T).unsqueeze(1).contiguous()                                # (S, 1, N, d)
+        jgx = R.expand(S, 1, n_pts, d, d).contiguous()                          # (S, 1, N, d, d)
+        sym = (gx, jgx, a.w_sym_reg)
     n_chunks = a.chunks or (2 if (use_dist and a.shard == "points") else 1)
     clos = BatchedClosure(x, dx, order, Q=Q, use_kron_product=use_kron, allow_constant=True,
-                          group=dist.group.WORLD if (use_dist and a.shard == "points") else None, n_chunks=n_chunks, engine=eng)
+                          group=dist.group.WORLD if (use_dist and a.shard == "points") else None, n_chunks=n_chunks, engine=eng,
+                          reversed_sym=sym)
     g = torch.Generator(device=dev)
     g.manual_seed(7 + rank)
     beta = torch.randn(S, Q.shape[1], generator=g, device=dev) * 0.3
@@ -148,9 +256,7 @@ def main():
     def step():
         return clos.evaluate(beta, const)
 
-    # W untimed warm-up steps as asked, topped up to >= 20 so that a small W does not leave the first timed launches on
-    # ramping clocks (the timed region below is exactly K steps either way)
-    for _ in range(max(a.warmup, 20)):
+    for _ in range(a.warmup):           # exactly W untimed warm-up steps (default 20: clocks settle within ~10)
         step()
     torch.cuda.synchronize()
     if use_dist:
@@ -158,27 +264,15 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps; HIP events bracket every fused-kernel launch ----
-    events = []
-    orig = eng.loss_grad
-
-    def timed_loss_grad(*args, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(*args, **kw)
-        e1.record()
-        events.append((e0, e1))
-        return out
-
-    eng.loss_grad = timed_loss_grad
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    eng.loss_grad = orig
+    with _KernelTimer(eng, "loss_grad") as t_lg, _KernelTimer(eng, "symreg_reversed") as t_sr:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     assert torch.isfinite(out[0]).all()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -186,28 +280,85 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    kern_all = sorted(e0.elapsed_time(e1) for e0, e1 in events)
-    kern_ms = sum(kern_all) / max(len(kern_all), 1)
-    launches_per_step = len(events) // max(a.steps, 1)
-    bytes_per_launch = (S / launches_per_step) * n_pts * (2 * 4 * d)        # read x and dx once: 16 B/point at d=2
-    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    launches_per_step = max(len(t_lg.events) // max(a.steps, 1), 1)
+    pts_per_launch = (S / launches_per_step) * n_pts
+    legs = [_leg(f"loss_grad_kernel<Library<2,{order},0>> (Theta + residual + loss + grad; last workgroup finalises)",
+                 pts_per_launch * (2 * 4 * d), t_lg.ms(), _pmc_traffic("loss_grad", pts_per_launch), bytes_per_point=2 * 4 * d,
+                 in_step=True)]
+    if sym is not None:
+        bpp = 4 * d + 1 * (4 * d + 4 * d * d)               # x + per group element (g(x), J_g(x)): 32 B/point at d = 2
+        legs.append(_leg(f"symreg_reversed_kernel<Library<2,{order},0>> (S4 on precomputed g(x), J_g(x))", pts_per_launch * bpp,
+                         t_sr.ms(), _pmc_traffic("symreg_reversed", pts_per_launch), bytes_per_point=bpp, in_step=True))
 
-    # ---- single-problem latency (the 50x2500x2 shape on its own is launch-latency bound) ----
-    single_us = float("nan")
+    # ---- Euler-flow pair of the infinitesimal regulariser (S2): K = 10 steps + tangent, and its reverse ----
+    single = {}
     if not a.profile:
+        S2 = min(S, 512)
+        n2 = S2 * n_pts
+        x2 = x[:S2].reshape(n2, d)
+        v2 = torch.randn(n2, d, device=dev) * 0.5
+        g1, g2 = torch.randn(n2, d, device=dev), torch.randn(n2, d, device=dev)
+        o2, f2, K2, dt2 = 2, 2, 10, 0.01                       # lv/noise99_eq_isymreg.cfg: order 2 + exp, int_t 0.1 / int_dt 0.01
+        xi2 = torch.randn(d, eng.lib_size(d, o2, f2), device=dev) * 0.05
+        for _ in range(2):
+            eng.euler_jvp(x2, v2, xi2, None, o2, f2, K2, dt2)
+            eng.euler_jvp_vjp(x2, v2, g1, g2, xi2, None, o2, f2, K2, dt2)
+        with _KernelTimer(eng, "euler_jvp") as t_ej, _KernelTimer(eng, "euler_jvp_vjp") as t_ev:
+            for _ in range(5):
+                eng.euler_jvp(x2, v2, xi2, None, o2, f2, K2, dt2)
+                eng.euler_jvp_vjp(x2, v2, g1, g2, xi2, None, o2, f2, K2, dt2)
+            torch.cuda.synchronize()
+        legs.append(_leg("euler_jvp_kernel<Library<2,2,2>> (S2: K = 10 Euler steps + tangent in registers)", n2 * 4 * 4 * d, t_ej.ms(),
+                         bytes_per_point=4 * 4 * d, in_step=False, limited_by="valu (10 library + tangent evaluations per 32 bytes)"))
+        legs.append(_leg("euler_jvp_vjp_kernel<Library<2,2,2>> (S2 reverse)", n2 * 6 * 4 * d, t_ev.ms(), bytes_per_point=6 * 4 * d,
+                         in_step=False, limited_by="valu (reverse sweep over the K steps)"))
+        del x2, v2, g1, g2
+
+        # ---- single problem (the 50x2500x2 shape on its own is launch-latency bound) ----
         x1, dx1 = x[0], dx[0]
         Xi1 = clos.xi_from(beta, const)[0].contiguous()
+        l1, gr1 = torch.empty(1, device=dev), torch.empty(d, clos.p, device=dev)
+        ws1 = eng.new_workspace(dev, eng.lib.symode_workspace_bytes(d, order, 0, 1, n_pts))
         for _ in range(20):
-            eng.loss_grad(x1, dx1, Xi1, None, order)
+            eng.loss_grad(x1, dx1, Xi1, None, order, out=(l1, gr1), ws=ws1)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.loss_grad(x1, dx1, Xi1, None, order, out=(l1, gr1), ws=ws1)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph, per = torch.cuda.CUDAGraph(), 20
+        with torch.cuda.graph(graph):
+            for _ in range(per):                                    # back-to-back launches, no host in between
+                eng.loss_grad(x1, dx1, Xi1, None, order, out=(l1, gr1), ws=ws1)
+        graph.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 200
         e0.record()
-        for _ in range(reps):
-            eng.loss_grad(x1, dx1, Xi1, None, order)
+        for _ in range(10):
+            graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        single_us = e0.elapsed_time(e1) * 1e3 / reps
+        kernel_us = e0.elapsed_time(e1) * 1e3 / (10 * per)
+        # closure as the L-BFGS trainer evaluates it: Xi in, [loss | grad] out, one launch, one sync (train._HostShadow)
+        from symode_amd.sindy import SINDyRegression
+        from symode_amd.train import _HostShadow
+        reg = SINDyRegression(d, order, False, False, threshold=0.01, device=dev)
+        sh = _HostShadow(reg, x1, dx1, numpy_vars=False)
+        with torch.no_grad():
+            for _ in range(20):
+                sh.evaluate()
+            tw = time.perf_counter()
+            for _ in range(200):
+                sh.evaluate()
+            closure_us = (time.perf_counter() - tw) * 1e6 / 200
+        single = {"shape": f"{a.n_ics}x{a.n_steps}x2", "launches_per_closure": 1 if sh.zero_copy else 2,
+                  "kernel_us": kernel_us, "closure_us": closure_us, "latency_us": kernel_us,
+                  "points_per_s": n_pts / (closure_us * 1e-6), "points_per_s_kernel": n_pts / (kernel_us * 1e-6),
+                  "note": "kernel_us: GPU time per closure launch (Theta + residual + loss + grad, finalised by the last workgroup), "
+                          "20 back-to-back launches replayed from a HIP graph; closure_us: host wall time of one closure of the "
+                          "L-BFGS trainer (coefficients in, [loss | grad] out through pinned memory, one launch, one sync)"}
 
     if rank != 0:
         dist.destroy_process_group()
@@ -215,43 +366,40 @@ def main():
 
     total_points = float(S) * n_pts * world * a.steps
     value = total_points / elapsed
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            rec = json.load(open(pmc))
-            per_point = rec.get("loss_grad_bytes_per_point")
-            if per_point is not None and abs(rec.get("points_per_launch", 0) - (S / launches_per_step) * n_pts) < 1:
-                traffic = rec["loss_grad_bytes_per_launch"]          # PMC pass taken on this very launch shape
-            elif per_point is not None:
-                traffic = per_point * (S / launches_per_step) * n_pts  # scaled from the profiled launch (streaming kernel)
-        except Exception:
-            traffic = None
+    legs = [leg for leg in legs if leg is not None]
+    in_step = [leg for leg in legs if leg.get("in_step")]
+    dominant = max(in_step, key=lambda leg: leg["kernel_ms"] * leg["launches"])
+    parts = "Xi from beta, fused Theta+residual+loss+grad kernel" + (", fused reversed sym-reg kernel" if sym is not None else "") + ", grad->beta"
+    metric = "trajectory-points/sec through Theta-build+residual+sym-reg" if sym is not None else \
+        "trajectory-points/sec through Theta-build+residual (no sym-reg leg: --sym_reg none)"
     res = {
-        "metric": "trajectory-points/sec through Theta-build+residual+sym-reg",
+        "metric": metric,
         "value": value, "unit": "points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"damped_oscillator n_ics={a.n_ics} steps={a.n_steps} dim=2 poly-order={order} "
                                f"EquivSINDy-c (so2), {S} (trajectory,seed) problems per GPU resident in HBM; "
-                               f"step = closure (Xi from beta, fused Theta+residual+loss+grad kernel, grad->beta"
+                               f"step = closure ({parts}"
                                f"{', RCCL all-reduce of [loss|grad]' if (use_dist and a.shard == 'points') else ''})",
-                   "points_per_step_per_gpu": S * n_pts, "library_terms": clos.p,
-                   "parallelism": f"{a.shard[:-1]}-shard x{world}" if world > 1 else "single"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "loss_grad_kernel<Library<2,5,0>> (+ finalize)", "kernel_ms": kern_ms, "kernel_ms_min": kern_all[0], "kernel_ms_median": kern_all[len(kern_all) // 2],
-                     "kernel_ms_max": kern_all[-1],
-                     "bytes_per_launch": bytes_per_launch, "launches_per_step": launches_per_step},
-        "single_problem": {"shape": f"{a.n_ics}x{a.n_steps}x2", "latency_us": single_us,
-                           "points_per_s": n_pts / (single_us * 1e-6)},
+                   "points_per_step_per_gpu": S * n_pts, "library_terms": clos.p, "sym_reg": a.sym_reg,
+                   "parallelism": f"{a.shard[:-1]}-shard x{world}" if world > 1 else "single", "ranks_observed": ranks_observed},
+        "roofline": {k: v for k, v in dominant.items() if k != "in_step"},
+        "roofline_legs": legs,
     }
+    if single:
+        res["single_problem"] = single
     if world == 1 and not a.no_cpu_baseline and not a.profile:
-        ns = min(S, 8)
+        ns = min(S, 4)
         Xi_s = clos.xi_from(beta, const)[:ns].cpu()
-        res["cpu_baseline"] = cpu_baseline(x[:ns].cpu(), dx[:ns].cpu(), Xi_s, order, a.cpu_seconds)
-        res["speedup_vs_cpu_batched"] = value / res["cpu_baseline"]["value"]
-        res["speedup_vs_cpu_single_problem"] = res["single_problem"]["points_per_s"] / res["cpu_baseline"]["value"]
+        sym_c = None if sym is None else (sym[0][:ns].cpu(), sym[1][:ns].cpu(), sym[2])
+        res["cpu_baseline"] = cpu_baseline(x[:ns].cpu(), dx[:ns].cpu(), Xi_s, order, a.cpu_seconds, sym_c)
+        if single:
+            # north_star's own comparison: Theta-build + residual (+ backward) at 50x2500x2, reference op sequence on the
+            # host cores vs one closure of the GPU trainer (wall time, launch and read-back included)
+            cpu1 = cpu_baseline(x[:1].cpu(), dx[:1].cpu(), Xi_s[:1], order, min(4.0, a.cpu_seconds), None)
+            single["cpu_points_per_s"] = cpu1["value"]
+            single["cpu_cores"] = cpu1["cores"]
+            single["speedup_vs_cpu"] = single["points_per_s"] / cpu1["value"]
     print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -119,6 +119,15 @@ int symode_symreg_reversed(const float* x, const float* gx, const float* jgx, in
                            int flags, const float* xi, const float* mask, float* loss_out, float* grad_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same regulariser for n_problems independent (trajectory, seed) problems in ONE launch:
+ * x (S, n, d), gx (S, n_g, n, d), jgx (S, n_g, n, d, d), xi / mask (S, d, p); loss (S), grad (S, d, p).
+ * inv_count as in symode_loss_grad (1/(n*d) for the plain mean; a rank holding a point shard passes 1/(n_global*d)
+ * and all-reduces).  replaces: the per-seed processes of run_scripts/lv_noise99_eq_rreg.sh, each evaluating
+ * model_utils.py:160-168 per closure. */
+int symode_symreg_reversed_batched(const float* x, const float* gx, const float* jgx, int n_g, long n_problems, long n, int d,
+                                   int order, int flags, const float* xi, const float* mask, float inv_count,
+                                   float* loss_out, float* grad_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Reverse mode of symode_forward, given g = dL/d(out) (n, d):
  *   grad_x (n, d) = J_Theta(x)^T (xi*mask)^T g   (skipped when grad_x is NULL),
  *   grad_xi (d, p) = (g^T Theta(x)) * mask.

@@ -20,7 +20,10 @@ from .engine import get_engine, library_flags
 
 class BatchedClosure:
     def __init__(self, x, dx, poly_order, include_sine=False, include_exp=False, Q=None, use_kron_product=True,
-                 allow_constant=True, group=None, world_size=None, n_chunks=1, engine=None):
+                 allow_constant=True, group=None, world_size=None, n_chunks=1, engine=None, reversed_sym=None):
+        """``reversed_sym = (gx (S, n_g, N_local, d), jgx (S, n_g, N_local, d, d), weight)`` adds  weight * the reversed
+        symmetry regulariser (model_utils.py:126-170 on precomputed (g(x), J_g(x))) to every problem's loss and gradient:
+        one more fused launch per chunk, summed into the same packed buffer before the collective."""
         assert x.dim() == 3 and x.shape == dx.shape, "x, dx must be (S, N_local, d)"
         self.engine = engine or get_engine()
         self.x, self.dx = x.contiguous(), dx.contiguous()
@@ -41,6 +44,12 @@ class BatchedClosure:
         bounds = torch.linspace(0, self.S, self.n_chunks + 1).long().tolist()
         self.chunks = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
         self.buffers = [torch.empty((b - a) * nacc, dtype=torch.float32, device=x.device) for a, b in self.chunks]
+        self.sym = None
+        if reversed_sym is not None:
+            gx, jgx, weight = reversed_sym
+            assert gx.dim() == 4 and gx.shape[0] == self.S and gx.shape[2:] == x.shape[1:] and jgx.shape == gx.shape + (self.d,)
+            self.sym = (gx.contiguous(), jgx.contiguous(), float(weight))
+            self.sym_buffers = [torch.empty_like(b) for b in self.buffers]
 
     # -- coefficient plumbing (batched get_Xi, sindy.py:169-176) ----------------------------
     def xi_from(self, beta, const=None):
@@ -65,7 +74,7 @@ class BatchedClosure:
     def loss_grad_xi(self, Xi, mask=None):
         """loss (S,), dloss/dXi (S, d, p) summed over all ranks' shards."""
         works = []
-        for (a, b), buf in zip(self.chunks, self.buffers):
+        for ci, ((a, b), buf) in enumerate(zip(self.chunks, self.buffers)):
             n = b - a
             loss = buf[:n]
             grad = buf[n:].view(n, self.d, self.p)
@@ -74,6 +83,16 @@ class BatchedClosure:
             if l.data_ptr() != loss.data_ptr():          # an engine that does not write in place
                 loss.copy_(l)
                 grad.copy_(g)
+            if self.sym is not None:
+                gx, jgx, weight = self.sym
+                sb = self.sym_buffers[ci]
+                sl, sg = sb[:n], sb[n:].view(n, self.d, self.p)
+                l2, g2 = self.engine.symreg_reversed(self.x[a:b], gx[a:b], jgx[a:b], Xi[a:b], None if mask is None else mask[a:b],
+                                                     self.order, self.flags, out=(sl, sg), inv_count=self.inv_count)
+                if l2.data_ptr() != sl.data_ptr():
+                    sl.copy_(l2)
+                    sg.copy_(g2)
+                buf.add_(sb, alpha=weight)
             if self.distributed:
                 works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:

@@ -200,18 +200,31 @@ int symode_symreg_linear(const float* z, long n, int d, int order, int flags, co
                                    (hipStream_t)stream);
 }
 
+int symode_symreg_reversed_batched(const float* x, const float* gx_, const float* jgx, int n_g, long n_problems, long n, int d,
+                                   int order, int flags, const float* xi, const float* mask, float inv_count,
+                                   float* loss_out, float* grad_out, void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 1 || n_g < 0 || n_problems < 1 || n_problems > 65535) return SYMODE_E_BADSIZE;
+    if (!x || !xi || !loss_out || !grad_out || (n_g > 0 && (!gx_ || !jgx))) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(gx_, 4) || misaligned(jgx, 4) || misaligned(xi, 4) || misaligned(mask, 4) ||
+        misaligned(loss_out, 4) || misaligned(grad_out, 4))
+        return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(n_problems, n);
+    int gx = grid_x_for(n, n_problems, ppt_for(d));
+    if (n_problems == 1 && gx <= 512) {
+        const int cap = small_grid_cap();
+        if (cap > 0 && gx > cap) gx = cap;
+    }
+    return (int)ops->symreg_reversed(x, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, loss_out, grad_out,
+                                     (double*)workspace, gx, (hipStream_t)stream);
+}
+
 int symode_symreg_reversed(const float* x, const float* gx_, const float* jgx, int n_g, long n, int d, int order,
                            int flags, const float* xi, const float* mask, float* loss_out, float* grad_out,
                            void* workspace, size_t workspace_bytes, void* stream) {
-    SYMODE_GET_OPS();
-    if (n < 1 || n_g < 0) return SYMODE_E_BADSIZE;
-    if (!x || !xi || !loss_out || !grad_out || (n_g > 0 && (!gx_ || !jgx))) return SYMODE_E_NULLPTR;
-    if (misaligned(x, 4) || misaligned(gx_, 4) || misaligned(jgx, 4) || misaligned(xi, 4) || misaligned(mask, 4))
-        return SYMODE_E_ALIGN;
-    SYMODE_CHECK_WS(1, n);
-    const int gx = grid_x_for(n, 1, 1);
-    return (int)ops->symreg_reversed(x, gx_, jgx, n_g, n, xi, mask, loss_out, grad_out, (double*)workspace, gx,
-                                     (hipStream_t)stream);
+    if (n < 1 || d < 1) return SYMODE_E_BADSIZE;
+    return symode_symreg_reversed_batched(x, gx_, jgx, n_g, 1, n, d, order, flags, xi, mask, 1.0f / ((float)n * (float)d),
+                                          loss_out, grad_out, workspace, workspace_bytes, stream);
 }
 
 int symode_vjp(const float* x, const float* g, long n, int d, int order, int flags, const float* xi, const float* mask,

@@ -36,8 +36,9 @@ struct LibOps {
                             float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st);
     hipError_t (*symreg_linear)(const float* z, long n, const float* xi, const float* mask, const float* L, int n_gen,
                                 float* loss, float* grad, double* ws, int gx, hipStream_t st);
-    hipError_t (*symreg_reversed)(const float* x, const float* gx_, const float* jgx, int n_g, long n, const float* xi,
-                                  const float* mask, float* loss, float* grad, double* ws, int gx, hipStream_t st);
+    hipError_t (*symreg_reversed)(const float* x, const float* gx_, const float* jgx, int n_g, long S, long n, const float* xi,
+                                  const float* mask, float inv_count, float* loss, float* grad, double* ws, int gx,
+                                  hipStream_t st);
     hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
                            int gx, hipStream_t st);
     hipError_t (*vjp)(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
@@ -931,56 +932,156 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
 // S4: reversed symmetry regulariser with precomputed (g(x), J_g(x))
 //   u = J_g(x) h(x) - h(g(x));  loss = sum_g mean(u^2);
 //   dloss/dXi[j,k] = (2/(N D)) sum ( (J_g^T u)_j th_k(x) - u_j th_k(g x) ).
+// Batched like K1: problem s = blockIdx.y owns x[s] (N, D), gx[s] (n_g, N, D), jgx[s] (n_g, N, D, D), xi[s], mask[s].
+// A pure stream (8 + n_g * 24 bytes per point at D = 2, each read once): every operand arrives as non-temporal
+// 16-byte vectors -- a chunk of PPT points is one vector of x, one of g(x) and PPT*D*D/4 consecutive vectors of J_g --
+// and a step issues the loads of two chunks before the arithmetic of either.
 // ---------------------------------------------------------------------------------------
+template <int D>
+struct JChunk {
+    static constexpr int NV = Chunk<D>::PPT * D * D / 4;              // dwordx4 per chunk of Jacobians
+    static_assert(Chunk<D>::PPT * D * D == NV * 4, "Jacobian chunk must be whole 16-byte vectors");
+};
+
 template <class Lib>
 __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gx,
-                                                                const float* __restrict__ jgx, int n_g, long N,
+                                                                const float* __restrict__ jgx, int n_g, long N, bool vec,
                                                                 const float* __restrict__ xi,
                                                                 const float* __restrict__ mask,
                                                                 double* __restrict__ ws, Finish fin) {
-    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NVJ = JChunk<D>::NV;
+    const long s = blockIdx.y;
+    const float* xs = x + s * N * D;
+    const float* gs = gx + s * (long)n_g * N * D;
+    const float* js = jgx + s * (long)n_g * N * D * D;
     float w[D * P];
-    load_xi<Lib>(xi, mask, 0, w);
+    load_xi<Lib>(xi, mask, s, w);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
-    for (long n = tid; n < N; n += nthreads) {
+
+    // one point against one group element: th, h belong to x (shared by all group elements of the point)
+    auto one = [&](const float (&th)[P], const float (&h)[D], const float (&gp)[D], const float (&J)[D * D]) {
+        float thg[P], hg[D], u[D], jtu[D];
+        Lib::eval(gp, thg);
+        apply_xi<Lib>(w, thg, hg);
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            float t = -hg[a];
+#pragma unroll
+            for (int b = 0; b < D; ++b) t = fmaf(J[a * D + b], h[b], t);
+            u[a] = t;
+            acc[0] = fmaf(t, t, acc[0]);
+        }
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            float t = 0.0f;
+#pragma unroll
+            for (int a = 0; a < D; ++a) t = fmaf(J[a * D + b], u[a], t);
+            jtu[b] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int k = 0; k < P; ++k) acc[1 + j * P + k] += jtu[j] * th[k] - u[j] * thg[k];
+    };
+    auto load_j = [&](const float* base, long c, float4 (&v)[NVJ]) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v* q = reinterpret_cast<const f4v*>(base) + c * NVJ;
+#pragma unroll
+        for (int i = 0; i < NVJ; ++i) {
+            const f4v t = __builtin_nontemporal_load(q + i);
+            v[i] = make_float4(t.x, t.y, t.z, t.w);
+        }
+    };
+    // the chunk's points against group element g, operands already in registers
+    auto chunk_g = [&](const float (&th)[PPT][P], const float (&h)[PPT][D], const float4 (&vg)[NV], const float4 (&vj)[NVJ]) {
+        float gp[PPT][D], jf[NVJ * 4];
+        unpack_chunk<D>(vg, gp);
+#pragma unroll
+        for (int i = 0; i < NVJ; ++i) {
+            jf[4 * i + 0] = vj[i].x;
+            jf[4 * i + 1] = vj[i].y;
+            jf[4 * i + 2] = vj[i].z;
+            jf[4 * i + 3] = vj[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            float J[D * D];
+#pragma unroll
+            for (int e = 0; e < D * D; ++e) J[e] = jf[i * D * D + e];
+            one(th[i], h[i], gp[i], J);
+        }
+    };
+    auto point = [&](long n) {
         float xp[D], th[P], h[D];
-        load_point<D>(x, n, xp);
+        load_point<D>(xs, n, xp);
         Lib::eval(xp, th);
         apply_xi<Lib>(w, th, h);
         for (int g = 0; g < n_g; ++g) {
-            float gp[D], J[D][D], thg[P], hg[D], u[D], jtu[D];
-            load_point<D>(gx + (long)g * N * D, n, gp);
-            const float* Jp = jgx + ((long)g * N + n) * D * D;
+            float gp[D], J[D * D];
+            load_point<D>(gs + (long)g * N * D, n, gp);
+            const float* Jp = js + ((long)g * N + n) * D * D;
 #pragma unroll
-            for (int a = 0; a < D; ++a)
-#pragma unroll
-                for (int b = 0; b < D; ++b) J[a][b] = Jp[a * D + b];
-            Lib::eval(gp, thg);
-            apply_xi<Lib>(w, thg, hg);
-#pragma unroll
-            for (int a = 0; a < D; ++a) {
-                float t = -hg[a];
-#pragma unroll
-                for (int b = 0; b < D; ++b) t = fmaf(J[a][b], h[b], t);
-                u[a] = t;
-                acc[0] = fmaf(t, t, acc[0]);
-            }
-#pragma unroll
-            for (int b = 0; b < D; ++b) {
-                float t = 0.0f;
-#pragma unroll
-                for (int a = 0; a < D; ++a) t = fmaf(J[a][b], u[a], t);
-                jtu[b] = t;
-            }
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-#pragma unroll
-                for (int k = 0; k < P; ++k) acc[1 + j * P + k] += jtu[j] * th[k] - u[j] * thg[k];
+            for (int e = 0; e < D * D; ++e) J[e] = Jp[e];
+            one(th, h, gp, J);
         }
+    };
+    auto eval_x = [&](const float4 (&vx)[NV], float (&th)[PPT][P], float (&h)[PPT][D]) {
+        float xp[PPT][D];
+        unpack_chunk<D>(vx, xp);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            Lib::eval(xp[i], th[i]);
+            apply_xi<Lib>(w, th[i], h[i]);
+        }
+    };
+
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    if (vec && n_g > 0) {
+        const long nchunks = N / PPT;
+        long c = tid;
+        for (; c + nthreads < nchunks; c += 2 * nthreads) {
+            // both chunks' x, g(x), J_g of the first group element in flight before any arithmetic
+            float4 ax[NV], bx[NV], ag[NV], bg[NV], aj[NVJ], bj[NVJ];
+            load_chunk_raw<D, true>(xs, c, ax);
+            load_chunk_raw<D, true>(gs, c, ag);
+            load_j(js, c, aj);
+            load_chunk_raw<D, true>(xs, c + nthreads, bx);
+            load_chunk_raw<D, true>(gs, c + nthreads, bg);
+            load_j(js, c + nthreads, bj);
+            float tha[PPT][P], ha[PPT][D], thb[PPT][P], hb[PPT][D];
+            eval_x(ax, tha, ha);
+            chunk_g(tha, ha, ag, aj);
+            eval_x(bx, thb, hb);
+            chunk_g(thb, hb, bg, bj);
+            for (int g = 1; g < n_g; ++g) {
+                const float* gg = gs + (long)g * N * D;
+                const float* jg = js + (long)g * N * D * D;
+                load_chunk_raw<D, true>(gg, c, ag);
+                load_j(jg, c, aj);
+                load_chunk_raw<D, true>(gg, c + nthreads, bg);
+                load_j(jg, c + nthreads, bj);
+                chunk_g(tha, ha, ag, aj);
+                chunk_g(thb, hb, bg, bj);
+            }
+        }
+        if (c < nchunks) {
+            float4 ax[NV], ag[NV], aj[NVJ];
+            load_chunk_raw<D, true>(xs, c, ax);
+            float tha[PPT][P], ha[PPT][D];
+            eval_x(ax, tha, ha);
+            for (int g = 0; g < n_g; ++g) {
+                load_chunk_raw<D, true>(gs + (long)g * N * D, c, ag);
+                load_j(js + (long)g * N * D * D, c, aj);
+                chunk_g(tha, ha, ag, aj);
+            }
+        }
+        const long n = nchunks * PPT + tid;
+        if (n < N) point(n);
+    } else {
+        for (long n = tid; n < N; n += nthreads) point(n);
     }
     emit_partials<NACC>(acc, ws, fin);
 }
@@ -1477,15 +1578,19 @@ hipError_t launch_symreg_linear(const float* z, long n, const float* xi, const f
 }
 
 template <class Lib>
-hipError_t launch_symreg_reversed(const float* x, const float* gxp, const float* jgx, int n_g, long n, const float* xi,
-                                  const float* mask, float* loss, float* grad, double* ws, int gx, hipStream_t st) {
-    constexpr int NACC = 1 + Lib::D * Lib::P;
+hipError_t launch_symreg_reversed(const float* x, const float* gxp, const float* jgx, int n_g, long S, long n, const float* xi,
+                                  const float* mask, float inv_count, float* loss, float* grad, double* ws, int gx,
+                                  hipStream_t st) {
+    constexpr int NACC = 1 + Lib::D * Lib::P, D = Lib::D;
     double* part = ws + WS_HEADER_DOUBLES;
-    const float inv = 1.0f / ((float)n * (float)Lib::D);
-    const Finish fin = make_finish(ws, mask, inv, 2.0f * inv, loss, grad);
-    symreg_reversed_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, gxp, jgx, n_g, n, xi, mask, part, fin);
+    const Finish fin = make_finish(ws, mask, inv_count, 2.0f * inv_count, loss, grad);
+    // 16-byte vectors need every slab (problem, group element) to start on a 16-byte boundary
+    const bool multi = S > 1 || n_g > 1;
+    const bool vec = ((uintptr_t)x % 16 == 0) && ((uintptr_t)gxp % 16 == 0) && ((uintptr_t)jgx % 16 == 0) &&
+                     (!multi || ((n * D) % 4 == 0 && (n * D * D) % 4 == 0));
+    symreg_reversed_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, gxp, jgx, n_g, n, vec, xi, mask, part, fin);
     SYMODE_LAUNCH_CHECK();
-    return launch_finalize(fin, part, 1, gx, NACC, st);
+    return launch_finalize(fin, part, S, gx, NACC, st);
 }
 
 template <class Lib>

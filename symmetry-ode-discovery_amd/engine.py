@@ -42,6 +42,8 @@ _SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_symreg_reversed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_symreg_reversed_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_long, c_int, c_int, c_int, c_void_p,
+                                               c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_vjp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
     "symode_forward_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -286,29 +288,41 @@ class HipEngine:
                                                   self._ptr(ws), ws.numel() * 8, self._stream(z)), "symode_symreg_linear")
         return loss[0], grad
 
-    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0, out=None, ws=None):
+    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0, out=None, ws=None, inv_count=None):
+        """Reversed symmetry regulariser on precomputed (g(x), J_g(x)).
+        One problem: x (N, d), gx (n_g, N, d), jgx (n_g, N, d, d), xi / mask (d, p) -> (loss scalar, grad (d, p)).
+        S problems in one launch: x (S, N, d), gx (S, n_g, N, d), jgx (S, n_g, N, d, d), xi / mask (S, d, p) -> ((S,), (S, d, p)).
+        ``xi`` / ``out`` may be pinned host tensors for the one-problem form; ``inv_count`` as in loss_grad."""
         x, gx, jgx = self._dev(x, "x"), self._dev(gx, "gx"), self._dev(jgx, "jgx")
+        batched = x.dim() == 3
+        S = x.shape[0] if batched else 1
         n, d = x.shape[-2], x.shape[-1]
-        n_g = gx.shape[0]
-        if gx.shape != (n_g, n, d) or jgx.shape != (n_g, n, d, d):
+        n_g = gx.shape[1] if batched else gx.shape[0]
+        want_g = (S, n_g, n, d) if batched else (n_g, n, d)
+        if tuple(gx.shape) != want_g or tuple(jgx.shape) != want_g + (d,):
             raise SymodeError(f"gx {tuple(gx.shape)} / jgx {tuple(jgx.shape)} do not match x {tuple(x.shape)}")
         xi = self._dev_or_pinned(xi, "xi")
         mask = None if mask is None else self._dev(mask, "mask")
-        p = self._check_coef(xi, mask, d, order, flags)
+        p = self._check_coef(xi, mask, d, order, flags, S)
         if out is None:
-            loss = torch.empty(1, dtype=torch.float32, device=x.device)
-            grad = torch.empty(d, p, dtype=torch.float32, device=x.device)
+            loss = torch.empty(S, dtype=torch.float32, device=x.device)
+            grad = torch.empty(S, d, p, dtype=torch.float32, device=x.device)
         else:
             loss, grad = (self._dev_or_pinned(o, "out") for o in out)
-            if loss.numel() != 1 or grad.numel() != d * p:
-                raise SymodeError("out buffers do not match (1,) / (d, p)")
+            if loss.numel() != S or grad.numel() != S * d * p:
+                raise SymodeError(f"out buffers hold {loss.numel()} / {grad.numel()} elements, expected {S} / {S * d * p}")
         if ws is None:
-            ws = self.workspace(x.device, d, order, flags, 1, n)
-        self._check(self.lib.symode_symreg_reversed(self._ptr(x), self._ptr(gx), self._ptr(jgx), n_g, n, d, order, flags,
-                                                    self._ptr(xi), self._ptr(mask), self._ptr(loss), self._ptr(grad),
-                                                    self._ptr(ws), ws.numel() * 8, self._stream(x)),
-                    "symode_symreg_reversed")
-        return loss[0], grad
+            ws = self.workspace(x.device, d, order, flags, S, n)
+        elif ws.numel() * 8 < self.lib.symode_workspace_bytes(d, order, flags, S, n):
+            raise SymodeError("private workspace too small for this call")
+        inv = 1.0 / (n * d) if inv_count is None else float(inv_count)
+        self._check(self.lib.symode_symreg_reversed_batched(self._ptr(x), self._ptr(gx), self._ptr(jgx), n_g, S, n, d, order,
+                                                            flags, self._ptr(xi), self._ptr(mask), inv, self._ptr(loss),
+                                                            self._ptr(grad), self._ptr(ws), ws.numel() * 8, self._stream(x)),
+                    "symode_symreg_reversed_batched")
+        if not batched:
+            return loss.reshape(-1)[0], grad.reshape(d, p)
+        return loss, grad
 
 
     def vjp(self, x, g, xi, mask, order, flags=0, need_grad_x=True):

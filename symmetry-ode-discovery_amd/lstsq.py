@@ -199,9 +199,26 @@ def lstsq_normal(G, C, m_rows: int, driver: str = "gelsy", rcond: float | None =
                                       -1.0 if rcond is None else float(rcond), W.ctypes.data, ctypes.addressof(rank))
     if rc != 0:
         if driver == "gels":
-            raise np.linalg.LinAlgError("singular normal equations under the full-rank (gels) driver")
+            return _singular_fallback(G, C, m_rows)
         raise RuntimeError(f"symode_host_lstsq_normal failed with code {rc}")
     return (W[:, 0] if squeeze else W), rank.value
+
+
+SINGULAR_RCOND = 1e-7      # on the triangular factor, i.e. cond(A^T A) > 1e14: singular to fp64 working accuracy
+_warned_singular = False
+
+
+def _singular_fallback(G, C, m_rows):
+    """The full-rank driver met exactly singular normal equations (a latent batch that lies in a subspace, a constraint
+    that leaves a column empty).  torch.linalg.lstsq(driver='gels') returns unusable numbers there without saying so;
+    here the rank-revealing solve takes over with a rank cut at fp64 working accuracy: the minimum-norm solution."""
+    global _warned_singular
+    if not _warned_singular:
+        import warnings
+        warnings.warn("singular normal equations under the full-rank (gels) driver: minimum-norm solution returned instead",
+                      RuntimeWarning)
+        _warned_singular = True
+    return lstsq_normal_py(G, C, m_rows, "gelsy", SINGULAR_RCOND)
 
 
 def lstsq_normal_py(G: np.ndarray, C: np.ndarray, m_rows: int, driver: str = "gelsy", rcond: float | None = None):
@@ -220,7 +237,10 @@ def lstsq_normal_py(G: np.ndarray, C: np.ndarray, m_rows: int, driver: str = "ge
         W = np.zeros((0, C.shape[1]))
         return (W[:, 0] if squeeze else W), 0
     if driver == "gels":
-        W = np.linalg.solve(G, C)                       # raises LinAlgError when singular
+        try:
+            W = np.linalg.solve(G, C)
+        except np.linalg.LinAlgError:
+            return _singular_fallback(G, C[:, 0] if squeeze else C, m_rows)
         return (W[:, 0] if squeeze else W), n
     if driver != "gelsy":
         raise ValueError(f"unknown lstsq driver {driver!r}")

@@ -81,11 +81,21 @@ class OracleEngine:
             loss.backward()
         return loss.detach(), reg.Xi.grad
 
-    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0):
-        d = x.shape[-1]
-        reg = O.OracleRegressor(d, order, *_fl(flags), Xi0=xi)
-        reg.mask = torch.ones_like(xi) if mask is None else mask
-        with torch.enable_grad():
-            loss = O.symreg_reversed_precomputed(x, list(gx), list(jgx), reg)
-            loss.backward()
-        return loss.detach(), reg.Xi.grad
+    def symreg_reversed(self, x, gx, jgx, xi, mask, order, flags=0, out=None, ws=None, inv_count=None):
+        batched = x.dim() == 3
+        X, GX, JGX = (x, gx, jgx) if batched else (x[None], gx[None], jgx[None])
+        S, n, d = X.shape
+        XI = xi.reshape(S, d, -1)
+        M = torch.ones_like(XI) if mask is None else mask.reshape(S, d, -1)
+        scale = 1.0 if inv_count is None else inv_count * n * d
+        losses, grads = [], []
+        for s in range(S):
+            reg = O.OracleRegressor(d, order, *_fl(flags), Xi0=XI[s])
+            reg.mask = M[s]
+            with torch.enable_grad():
+                loss = O.symreg_reversed_precomputed(X[s], list(GX[s]), list(JGX[s]), reg)
+                loss.backward()
+            losses.append(loss.detach() * scale)
+            grads.append(reg.Xi.grad * scale)
+        loss, grad = torch.stack(losses), torch.stack(grads)
+        return (loss, grad) if batched else (loss[0], grad[0])

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_chunks, constrained, out_dir):
+def _worker(rank, world, port, n_chunks, constrained, out_dir, with_sym=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,8 +32,14 @@ def _worker(rank, world, port, n_chunks, constrained, out_dir):
     Q = None
     if constrained:
         Q, uk = constraint_Q([torch.tensor([[0.0, 1.0], [-1.0, 0.0]])], d, order)
+    sym = None
+    if with_sym:                                  # reversed symmetry regulariser on precomputed (g(x), J_g(x)), sharded like x
+        R = torch.matrix_exp(0.05 * torch.tensor([[0.0, 1.0], [-1.0, 0.0]]))
+        gx = (x @ R.T + 0.01 * torch.randn(S, n, d, generator=g)).unsqueeze(1)
+        jgx = (R + 0.01 * torch.randn(S, 1, n, d, d, generator=g))
+        sym = (gx[:, :, lo:hi].contiguous(), jgx[:, :, lo:hi].contiguous(), 0.1)
     clos = BatchedClosure(x[:, lo:hi].contiguous(), dx[:, lo:hi].contiguous(), order, Q=Q, use_kron_product=True,
-                          allow_constant=True, group=dist.group.WORLD, n_chunks=n_chunks, engine=OracleEngine())
+                          allow_constant=True, group=dist.group.WORLD, n_chunks=n_chunks, engine=OracleEngine(), reversed_sym=sym)
     if constrained:
         beta, const = torch.randn(S, Q.shape[1], generator=g), torch.randn(S, d, 1, generator=g)
         loss, gb, gc = clos.evaluate(beta, const)
@@ -48,10 +54,32 @@ def _worker(rank, world, port, n_chunks, constrained, out_dir):
     dist.destroy_process_group()
 
 
-def _run(tmp_path, n_chunks, constrained):
+def _run(tmp_path, n_chunks, constrained, with_sym=False):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_chunks, constrained, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, n_chunks, constrained, str(tmp_path), with_sym), nprocs=2, join=True)
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+
+
+def test_point_sharded_closure_with_reversed_symmetry_term(tmp_path):
+    """MSE + 0.1 * reversed sym-reg per problem, points (and their g(x), J_g(x)) split over two ranks: the all-reduced
+    packed buffer equals the full-batch closure of the oracle."""
+    r0, r1 = _run(tmp_path, n_chunks=2, constrained=False, with_sym=True)
+    g = torch.Generator().manual_seed(0)
+    S, n, d, order = 5, 600, 2, 3
+    x, dx = torch.randn(S, n, d, generator=g) * 0.7, torch.randn(S, n, d, generator=g)
+    R = torch.matrix_exp(0.05 * torch.tensor([[0.0, 1.0], [-1.0, 0.0]]))
+    gx = (x @ R.T + 0.01 * torch.randn(S, n, d, generator=g)).unsqueeze(1)
+    jgx = (R + 0.01 * torch.randn(S, 1, n, d, d, generator=g))
+    Xi = torch.randn(S, d, 10, generator=g)
+    mask = (torch.rand(S, d, 10, generator=g) > 0.3).float()
+    assert np.array_equal(r0["loss"], r1["loss"]) and np.array_equal(r0["grad"], r1["grad"])
+    for s in range(S):
+        reg = O.OracleRegressor(d, order, Xi0=Xi[s])
+        reg.mask = mask[s]
+        loss = torch.nn.functional.mse_loss(reg(x[s]), dx[s]) + 0.1 * O.symreg_reversed_precomputed(x[s], list(gx[s]), list(jgx[s]), reg)
+        loss.backward()
+        assert np.isclose(r0["loss"][s], loss.item(), rtol=1e-5)
+        assert np.allclose(r0["grad"][s], (reg.Xi.grad * mask[s]).numpy(), rtol=1e-4, atol=1e-6)
 
 
 def test_point_sharded_closure_matches_full_batch(tmp_path):

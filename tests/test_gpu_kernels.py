@@ -492,3 +492,55 @@ def test_zero_copy_closure_matches_copy_path(eng):
     sh2 = _HostShadow(reg, x, dx, numpy_vars=False, use_graph=True, zero_copy=False)
     _, vals2, grads2 = sh2.evaluate()
     assert torch.equal(vals[0], vals2[0]) and torch.equal(grads[0], grads2[0])
+
+
+# ------------------------------------------------------------- batched reversed symmetry regulariser
+@pytest.mark.parametrize("S,n,n_g,d,order,fl", [(1, 20000, 1, 2, 2, 2), (3, 4096, 2, 2, 3, 0), (2, 1001, 1, 2, 5, 0), (1, 777, 3, 3, 2, 1),
+                                                (4, 512, 1, 1, 4, 0), (2, 300, 2, 4, 2, 0)])
+def test_symreg_reversed_batched_vs_oracle(eng, S, n, n_g, d, order, fl):
+    """symode_symreg_reversed_batched (16-byte non-temporal chunk loads of x, g(x), J_g; ragged tails and unaligned slabs
+    fall back to per-point loads) against the oracle's model_utils.py:166-168 with the explicit matvec."""
+    torch.manual_seed(S * 100 + n)
+    p = eng.lib_size(d, order, fl)
+    x = torch.randn(S, n, d) * 0.5
+    gx = x[:, None] + 0.05 * torch.randn(S, n_g, n, d)
+    jgx = torch.eye(d) + 0.05 * torch.randn(S, n_g, n, d, d)
+    xi = torch.randn(S, d, p) * 0.3
+    mask = (torch.rand(S, d, p) > 0.25).float()
+    loss, grad = eng.symreg_reversed(x.cuda(), gx.cuda(), jgx.cuda(), xi.cuda(), mask.cuda(), order, fl)
+    assert loss.shape == (S,) and grad.shape == (S, d, p)
+    for s in range(S):
+        reg = O.OracleRegressor(d, order, bool(fl & 1), bool(fl & 2), Xi0=xi[s])
+        reg.mask = mask[s]
+        want = O.symreg_reversed_precomputed(x[s], list(gx[s]), list(jgx[s]), reg)
+        want.backward()
+        assert np.isclose(loss[s].item(), want.item(), rtol=2e-5), (s, loss[s].item(), want.item())
+        assert_close_scaled(grad[s].cpu(), reg.Xi.grad * mask[s], 3e-5, f"symreg_reversed grad, problem {s}")
+    # the one-problem form (and an unaligned view of it) gives the same numbers as row 0 of the batch
+    l1, g1 = eng.symreg_reversed(x[0].cuda(), gx[0].cuda(), jgx[0].cuda(), xi[0].cuda(), mask[0].cuda(), order, fl)
+    assert np.isclose(l1.item(), loss[0].item(), rtol=1e-6)
+    pad = torch.zeros(n * d + 1).cuda()
+    xu = pad[1:].view(n, d)
+    xu.copy_(x[0])
+    l2, g2 = eng.symreg_reversed(xu, gx[0].cuda(), jgx[0].cuda(), xi[0].cuda(), mask[0].cuda(), order, fl)
+    assert np.isclose(l2.item(), l1.item(), rtol=1e-5)
+    assert_close_scaled(g2.cpu(), g1.cpu(), 1e-5, "unaligned x")
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with no torchrun environment spawns two ranks itself; on this one-GPU box both use
+    cuda:0 and the collectives go through gloo (--rehearse_gloo).  The JSON line must say two ranks ran."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse_gloo", "--problems", "64", "--steps", "3",
+                          "--warmup", "1", "--no_cpu_baseline", "--profile", "--master_port", "29533"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks_observed"] == 2 and rec["warmup"] == 1 and rec["steps"] == 3
+    assert rec["metric"].endswith("sym-reg") and len(rec["roofline_legs"]) == 2 and rec["value"] > 0

@@ -70,7 +70,8 @@ def config2(S):
 def test_config2_lv_infinitesimal_regulariser_full_size(S, config2, split):
     """Closure of train.py:663-679 with sym_reg_type 'i': MSE + 0.1 * symmreg_i through the K = 10 Euler flow.
     Tolerances: fp32 end to end on both sides, through a 512 x 5 MLP and its decoder tangent (hipBLASLt on the GPU,
-    MKL on the host): value 1e-4, gradient 1e-3 of its scale (the relative loss is a ratio of two batch means)."""
+    MKL on the host): MSE 1e-5, regulariser value and gradient 3e-5 of their scale (measured on MI355X: 6.6e-6 and
+    3.6e-6; the relative loss is a ratio of two batch means)."""
     from symode_amd import model_utils as MU
     x, dx, ae, gen = config2
     assert x.shape == (20000, 2)
@@ -102,8 +103,8 @@ def test_config2_lv_infinitesimal_regulariser_full_size(S, config2, split):
     e_grad = _scaled_err(r.Xi.grad.cpu().numpy(), gw)
     print(f"config2 sym_reg_type i (split={split}): mse rel err {e_mse:.2e}, sym rel err {e_sym:.2e}, grad scaled err {e_grad:.2e}")
     assert e_mse <= 1e-5, e_mse
-    assert e_sym <= 1e-4, e_sym
-    assert e_grad <= 1e-3, e_grad
+    assert e_sym <= 3e-5, e_sym
+    assert e_grad <= 3e-5, e_grad
 
 
 # ------------------------------------------------------------------------------------------------ 1b
@@ -133,9 +134,12 @@ def _oracle_run(g, tag):
 @pytest.mark.parametrize("tag", ["dosc_sindy", "dosc_esindy", "selkov_sindy"])
 def test_hip_closure_along_the_recorded_lbfgs_trajectory(S, golden, tag):
     """Every closure point (Xi, mask) the pinned oracle run visits -- from the random start to the converged sparse
-    model -- evaluated by ONE batched launch of the fused kernel: loss and gradient within rtol 1e-5 of the oracle's.
-    This is what licenses the looser end-of-run coefficient tolerance of the trainer tests: both runs follow the same
-    map, evaluated to 1e-5, until L-BFGS's own stopping ball (update norm < 1e-3, train.py:705)."""
+    model -- evaluated by ONE batched launch of the fused kernel: loss within rtol 1e-5 of the oracle's, gradient within
+    1e-5 of the size of its summands, 2/(N d) sum_n |r_nj| |Theta_nk| (near the optimum the gradient itself is the
+    cancellation residue of those summands, so its own magnitude is no yardstick; where it is not small it is also
+    checked against its max-norm at 2e-5).  This is what licenses the looser end-of-run coefficient tolerance of the
+    trainer tests: both runs follow the same map, evaluated to 1e-5, until L-BFGS's own stopping ball (update norm
+    < 1e-3, train.py:705)."""
     g = golden("f4_lbfgs")
     reg, hist, x, dx, order = _oracle_run(g, tag)
     trace = reg.trace
@@ -148,16 +152,24 @@ def test_hip_closure_along_the_recorded_lbfgs_trajectory(S, golden, tag):
     DX = dx.to(DEV)[None].expand(n, -1, -1).contiguous()
     loss, grad = eng.loss_grad(X, DX, Xi, M, order)
     loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
-    worst_l = worst_g = 0.0
+    worst_l = worst_g = worst_rel = 0.0
+    th = O.theta(x, order).double()
     for k, (a, b) in enumerate(trace):
         wl, wg = O.mse_loss_and_grad(x, dx, a, b, order)
         wl, wg = wl.item(), wg.numpy()
+        r = (th @ (a * b).double().T - dx.double()).abs()
+        summands = (2.0 / r.numel()) * (r.T @ th.abs()).numpy()                 # (d, p): size of what each entry adds up
         # losses at the 1e-9 floor of a noise-free fit are sums of squared fp32 rounding errors of the residual itself
         worst_l = max(worst_l, abs(loss[k] - wl) / max(abs(wl), 1e-7))
-        worst_g = max(worst_g, np.abs(grad[k] - wg).max() / max(np.abs(wg).max(), 1e-6))
-    print(f"{tag}: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad scaled err {worst_g:.2e}")
+        live = b.numpy() > 0
+        worst_g = max(worst_g, (np.abs(grad[k] - wg)[live] / summands[live]).max())
+        if np.abs(wg).max() > 1e-2 * summands[live].max():                      # a gradient that is not cancellation residue
+            worst_rel = max(worst_rel, np.abs(grad[k] - wg).max() / np.abs(wg).max())
+    print(f"{tag}: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad err vs summands {worst_g:.2e}, "
+          f"vs max-norm (non-degenerate points) {worst_rel:.2e}")
     assert worst_l <= 1e-5, worst_l
-    assert worst_g <= 2e-5, worst_g
+    assert worst_g <= 1e-5, worst_g
+    assert worst_rel <= 2e-5, worst_rel
 
 
 @pytest.mark.parametrize("tag", ["dosc_sindy", "dosc_esindy", "selkov_sindy"])
