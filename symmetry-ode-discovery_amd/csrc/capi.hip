@@ -236,7 +236,7 @@ int symode_vjp(const float* x, const float* g, long n, int d, int order, int fla
         misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = grid_x_for(n, 1, 1);
+    const int gx = grid_x_for(n, 1, ppt_for(d));
     return (int)ops->vjp(x, g, n, xi, mask, grad_x, grad_xi, (double*)workspace, gx, (hipStream_t)stream);
 }
 
@@ -262,7 +262,7 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
         misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = grid_x_for(n, 1, 1);
+    const int gx = grid_x_for(n, 1, ppt_for(d));
     return (int)ops->jvp_vjp(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, grad_xi, (double*)workspace, gx,
                              (hipStream_t)stream);
 }
@@ -299,7 +299,7 @@ int symode_euler_jvp_vjp(const float* x, const float* v, const float* g_x, const
         misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = grid_x_for(n, 1, 1);
+    const int gx = grid_x_for(n, 1, ppt_for(d));
     return (int)ops->euler_jvp_vjp(x, v, g_x, g_t, n, xi, mask, n_steps, dt, grad_x, grad_v, grad_xi,
                                    (double*)workspace, gx, (hipStream_t)stream);
 }

@@ -90,7 +90,7 @@ constexpr int VGPR_XI_MAX = 48;     // up to here the masked coefficients simply
 constexpr int SGPR_XI_MAX = 64;     // VGPR_XI_MAX < D*P <= this: Xi in SGPRs (the wave has ~100 of them: d = 3 order 3, d = 4 order 2)
 
 // Masked coefficients of problem s into registers (uniform across the block -> scalar loads).
-template <class Lib>
+template <class Lib, int SGPR_FROM = VGPR_XI_MAX + 1>
 __device__ __forceinline__ void load_xi(const float* __restrict__ xi, const float* __restrict__ mask, long s,
                                         float (&w)[Lib::D * Lib::P]) {
     constexpr int DP = Lib::D * Lib::P;
@@ -106,7 +106,8 @@ __device__ __forceinline__ void load_xi(const float* __restrict__ xi, const floa
     // (constant-bus read; measured with the register-ring kernel: Xi in VGPRs +1.5 % at d = 2 order 5, +4.5 % at order 3).
     // Mid-size libraries (48 < D*P <= 64: d = 3 order 3, d = 4 order 2) are short of registers instead, so their
     // coefficients -- wave-uniform values -- go back to the scalar file and the D*P VGPRs become occupancy (6.4 -> 6.8 TB/s).
-    if constexpr (DP > VGPR_XI_MAX && DP <= SGPR_XI_MAX) {
+    // (SGPR_FROM: kernels with more per-point state than K1 move the coefficients out of the vector file earlier.)
+    if constexpr (DP >= SGPR_FROM && DP <= SGPR_XI_MAX) {
 #pragma unroll
         for (int i = 0; i < DP; ++i)
             w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[i])));
@@ -183,14 +184,16 @@ __global__ __launch_bounds__(BLOCK) void forward_kernel(const float* __restrict_
     constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
     float w[D * Lib::P];
     load_xi<Lib>(xi, mask, 0, w);
-    for_each_point<D, BLOCK>(
-        N, vec,
-        [&](long c) {
-            float xp[PPT][D], h[PPT][D];
-            load_chunk<D>(x, c, xp);
+    struct Ops {
+        float x[PPT][D];
+    };
+    for_each_chunk2<D, BLOCK, Ops>(
+        N, vec, [&](long c, Ops& o) { load_chunk<D>(x, c, o.x); },
+        [&](long c, Ops& o) {
+            float h[PPT][D];
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) rhs<Lib>(w, xp[i], h[i]);
-            store_chunk<D>(out, c, h);
+            for (int i = 0; i < PPT; ++i) rhs<Lib>(w, o.x[i], h[i]);
+            store_chunk_nt<D>(out, c, h);
         },
         [&](long n) {
             float xp[D], h[D];
@@ -266,14 +269,15 @@ __global__ __launch_bounds__(BLOCK) void odeint_kernel(const float* __restrict__
     constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
     float w[D * Lib::P];
     load_xi<Lib>(xi, mask, 0, w);
-    for_each_point<D, BLOCK>(
-        N, vec,
-        [&](long c) {
-            float xp[PPT][D];
-            load_chunk<D>(x, c, xp);
+    struct Ops {
+        float x[PPT][D];
+    };
+    for_each_chunk2<D, BLOCK, Ops>(
+        N, vec, [&](long c, Ops& o) { load_chunk<D>(x, c, o.x); },
+        [&](long c, Ops& o) {
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) integrate<Lib>(w, xp[i], n_steps, dt, method);
-            store_chunk<D>(out, c, xp);
+            for (int i = 0; i < PPT; ++i) integrate<Lib>(w, o.x[i], n_steps, dt, method);
+            store_chunk_nt<D>(out, c, o.x);
         },
         [&](long n) {
             float xp[D];
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
     const float* gs = gx + s * (long)n_g * N * D;
     const float* js = jgx + s * (long)n_g * N * D * D;
     float w[D * P];
-    load_xi<Lib>(xi, mask, s, w);
+    load_xi<Lib, 32>(xi, mask, s, w);          // two libraries per point live here: Xi in SGPRs from d*p = 32 (3 waves/SIMD at order 5)
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < D; ++j)
 #pragma unroll
-            for (int k = 0; k < P; ++k) acc[1 + j * P + k] += jtu[j] * th[k] - u[j] * thg[k];
+            for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(jtu[j], th[k], fmaf(-u[j], thg[k], acc[1 + j * P + k]));
     };
     auto load_j = [&](const float* base, long c, float4 (&v)[NVJ]) {
         typedef float f4v __attribute__((ext_vector_type(4)));
@@ -1039,6 +1043,18 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
     };
 
     const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    // one chunk: its points' Theta(x), h(x) are formed once and live only while this chunk's group elements are visited
+    auto chunk_all = [&](long c, const float4 (&vx)[NV], const float4 (&vg)[NV], const float4 (&vj)[NVJ]) {
+        float th[PPT][P], h[PPT][D];
+        eval_x(vx, th, h);
+        chunk_g(th, h, vg, vj);
+        for (int g = 1; g < n_g; ++g) {
+            float4 ng[NV], nj[NVJ];
+            load_chunk_raw<D, true>(gs + (long)g * N * D, c, ng);
+            load_j(js + (long)g * N * D * D, c, nj);
+            chunk_g(th, h, ng, nj);
+        }
+    };
     if (vec && n_g > 0) {
         const long nchunks = N / PPT;
         long c = tid;
@@ -1051,32 +1067,15 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
             load_chunk_raw<D, true>(xs, c + nthreads, bx);
             load_chunk_raw<D, true>(gs, c + nthreads, bg);
             load_j(js, c + nthreads, bj);
-            float tha[PPT][P], ha[PPT][D], thb[PPT][P], hb[PPT][D];
-            eval_x(ax, tha, ha);
-            chunk_g(tha, ha, ag, aj);
-            eval_x(bx, thb, hb);
-            chunk_g(thb, hb, bg, bj);
-            for (int g = 1; g < n_g; ++g) {
-                const float* gg = gs + (long)g * N * D;
-                const float* jg = js + (long)g * N * D * D;
-                load_chunk_raw<D, true>(gg, c, ag);
-                load_j(jg, c, aj);
-                load_chunk_raw<D, true>(gg, c + nthreads, bg);
-                load_j(jg, c + nthreads, bj);
-                chunk_g(tha, ha, ag, aj);
-                chunk_g(thb, hb, bg, bj);
-            }
+            chunk_all(c, ax, ag, aj);
+            chunk_all(c + nthreads, bx, bg, bj);
         }
         if (c < nchunks) {
             float4 ax[NV], ag[NV], aj[NVJ];
             load_chunk_raw<D, true>(xs, c, ax);
-            float tha[PPT][P], ha[PPT][D];
-            eval_x(ax, tha, ha);
-            for (int g = 0; g < n_g; ++g) {
-                load_chunk_raw<D, true>(gs + (long)g * N * D, c, ag);
-                load_j(js + (long)g * N * D * D, c, aj);
-                chunk_g(tha, ha, ag, aj);
-            }
+            load_chunk_raw<D, true>(gs, c, ag);
+            load_j(js, c, aj);
+            chunk_all(c, ax, ag, aj);
         }
         const long n = nchunks * PPT + tid;
         if (n < N) point(n);
@@ -1092,27 +1091,24 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
 //   grad_xi   = (sum_n g_n Theta(x_n)^T) * mask        (through the partial-sum epilogue)
 // ---------------------------------------------------------------------------------------
 template <class Lib>
-__global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x, const float* __restrict__ g, long N,
+__global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x, const float* __restrict__ g, long N, bool vec,
                                                     const float* __restrict__ xi, const float* __restrict__ mask,
                                                     float* __restrict__ grad_x, double* __restrict__ ws, Finish fin) {
-    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
-    for (long n = tid; n < N; n += nthreads) {
-        float xp[D], gp[D], th[P];
-        load_point<D>(x, n, xp);
-        load_point<D>(g, n, gp);
+    auto one = [&](const float (&xp)[D], const float (&gp)[D], float (&bx)[D]) {
+        float th[P];
         Lib::eval(xp, th);
 #pragma unroll
         for (int j = 0; j < D; ++j)
 #pragma unroll
             for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(gp[j], th[k], acc[1 + j * P + k]);
         if (grad_x != nullptr) {
-            float bar[P], bx[D];
+            float bar[P];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
                 float t = 0.0f;
@@ -1121,60 +1117,91 @@ __global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x,
                 bar[k] = t;
             }
             Lib::vjp(xp, th, bar, bx);
-            store_point<D>(grad_x, n, bx);
         }
-    }
+    };
+    struct Ops {
+        float x[PPT][D], g[PPT][D];
+    };
+    for_each_chunk2<D, BLOCK, Ops>(
+        N, vec,
+        [&](long c, Ops& o) {
+            load_chunk<D>(x, c, o.x);
+            load_chunk<D>(g, c, o.g);
+        },
+        [&](long c, Ops& o) {
+            float bx[PPT][D];
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) one(o.x[i], o.g[i], bx[i]);
+            if (grad_x != nullptr) store_chunk_nt<D>(grad_x, c, bx);
+        },
+        [&](long n) {
+            float xp[D], gp[D], bx[D];
+            load_point<D>(x, n, xp);
+            load_point<D>(g, n, gp);
+            one(xp, gp, bx);
+            if (grad_x != nullptr) store_point<D>(grad_x, n, bx);
+        });
     emit_partials<NACC>(acc, ws, fin);
 }
 
 // out = Theta(x) Xi_m^T and jv = (J_Theta(x) v) Xi_m^T in one pass (forward-mode tangent).
 template <class Lib>
 __global__ __launch_bounds__(BLOCK) void forward_jvp_kernel(const float* __restrict__ x, const float* __restrict__ v,
-                                                            long N, const float* __restrict__ xi,
+                                                            long N, bool vec, const float* __restrict__ xi,
                                                             const float* __restrict__ mask, float* __restrict__ out,
                                                             float* __restrict__ jv) {
-    constexpr int D = Lib::D, P = Lib::P;
+    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
-    for (long n = tid; n < N; n += nthreads) {
-        float xp[D], vp[D], th[P], dth[P], h[D], t[D];
-        load_point<D>(x, n, xp);
-        load_point<D>(v, n, vp);
+    auto one = [&](const float (&xp)[D], const float (&vp)[D], float (&h)[D], float (&t)[D]) {
+        float th[P], dth[P];
         Lib::eval_jvp(xp, vp, th, dth);
         apply_xi<Lib>(w, th, h);
         apply_xi<Lib>(w, dth, t);
-        if (out != nullptr) store_point<D>(out, n, h);
-        store_point<D>(jv, n, t);
-    }
+    };
+    struct Ops {
+        float x[PPT][D], v[PPT][D];
+    };
+    for_each_chunk2<D, BLOCK, Ops>(
+        N, vec,
+        [&](long c, Ops& o) {
+            load_chunk<D>(x, c, o.x);
+            load_chunk<D>(v, c, o.v);
+        },
+        [&](long c, Ops& o) {
+            float h[PPT][D], t[PPT][D];
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) one(o.x[i], o.v[i], h[i], t[i]);
+            if (out != nullptr) store_chunk_nt<D>(out, c, h);
+            store_chunk_nt<D>(jv, c, t);
+        },
+        [&](long n) {
+            float xp[D], vp[D], h[D], t[D];
+            load_point<D>(x, n, xp);
+            load_point<D>(v, n, vp);
+            one(xp, vp, h, t);
+            if (out != nullptr) store_point<D>(out, n, h);
+            store_point<D>(jv, n, t);
+        });
 }
 
 // Reverse mode of forward_jvp_kernel: upstream g_out on out (may be null) and g_jv on jv.
 template <class Lib>
 __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                         const float* __restrict__ g_out,
-                                                        const float* __restrict__ g_jv, long N,
+                                                        const float* __restrict__ g_jv, long N, bool vec,
                                                         const float* __restrict__ xi, const float* __restrict__ mask,
                                                         float* __restrict__ grad_x, float* __restrict__ grad_v,
                                                         double* __restrict__ ws, Finish fin) {
-    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
-    for (long n = tid; n < N; n += nthreads) {
-        float xp[D], vp[D], go[D], gt[D], th[P], dth[P], bar[P], dbar[P], bx[D], bv[D];
-        load_point<D>(x, n, xp);
-        load_point<D>(v, n, vp);
-        load_point<D>(g_jv, n, gt);
-        if (g_out != nullptr) {
-            load_point<D>(g_out, n, go);
-        } else {
-#pragma unroll
-            for (int j = 0; j < D; ++j) go[j] = 0.0f;
-        }
+    auto one = [&](const float (&xp)[D], const float (&vp)[D], const float (&go)[D], const float (&gt)[D], float (&bx)[D],
+                   float (&bv)[D]) {
+        float th[P], dth[P], bar[P], dbar[P];
         Lib::eval_jvp(xp, vp, th, dth);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -1189,9 +1216,47 @@ __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict_
             dbar[k] = c;
         }
         Lib::vjp_of_jvp(xp, vp, th, dth, bar, dbar, bx, bv);
-        store_point<D>(grad_x, n, bx);
-        store_point<D>(grad_v, n, bv);
-    }
+    };
+    struct Ops {
+        float x[PPT][D], v[PPT][D], go[PPT][D], gt[PPT][D];
+    };
+    for_each_chunk2<D, BLOCK, Ops>(
+        N, vec,
+        [&](long c, Ops& o) {
+            load_chunk<D>(x, c, o.x);
+            load_chunk<D>(v, c, o.v);
+            load_chunk<D>(g_jv, c, o.gt);
+            if (g_out != nullptr) {
+                load_chunk<D>(g_out, c, o.go);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) o.go[i][j] = 0.0f;
+            }
+        },
+        [&](long c, Ops& o) {
+            float bx[PPT][D], bv[PPT][D];
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) one(o.x[i], o.v[i], o.go[i], o.gt[i], bx[i], bv[i]);
+            store_chunk_nt<D>(grad_x, c, bx);
+            store_chunk_nt<D>(grad_v, c, bv);
+        },
+        [&](long n) {
+            float xp[D], vp[D], go[D], gt[D], bx[D], bv[D];
+            load_point<D>(x, n, xp);
+            load_point<D>(v, n, vp);
+            load_point<D>(g_jv, n, gt);
+            if (g_out != nullptr) {
+                load_point<D>(g_out, n, go);
+            } else {
+#pragma unroll
+                for (int j = 0; j < D; ++j) go[j] = 0.0f;
+            }
+            one(xp, vp, go, gt, bx, bv);
+            store_point<D>(grad_x, n, bx);
+            store_point<D>(grad_v, n, bv);
+        });
     emit_partials<NACC>(acc, ws, fin);
 }
 
@@ -1278,52 +1343,92 @@ __device__ __forceinline__ void euler_tangent_steps(const float (&w)[Lib::D * Li
 
 template <class Lib>
 __global__ __launch_bounds__(BLOCK) void euler_jvp_kernel(const float* __restrict__ x, const float* __restrict__ v,
-                                                          long N, const float* __restrict__ xi,
+                                                          long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, int n_steps, float dt,
                                                           float* __restrict__ x_out, float* __restrict__ t_out) {
-    constexpr int D = Lib::D;
+    constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
     float w[D * Lib::P];
     load_xi<Lib>(xi, mask, 0, w);
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
-    for (long n = tid; n < N; n += nthreads) {
-        float xp[D], tp[D];
-        load_point<D>(x, n, xp);
-        load_point<D>(v, n, tp);
-        euler_tangent_steps<Lib>(w, xp, tp, n_steps, dt);
-        store_point<D>(x_out, n, xp);
-        store_point<D>(t_out, n, tp);
-    }
+    struct Ops {
+        float x[PPT][D], t[PPT][D];
+    };
+    for_each_chunk2<D, BLOCK, Ops>(
+        N, vec,
+        [&](long c, Ops& o) {
+            load_chunk<D>(x, c, o.x);
+            load_chunk<D>(v, c, o.t);
+        },
+        [&](long c, Ops& o) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) euler_tangent_steps<Lib>(w, o.x[i], o.t[i], n_steps, dt);
+            store_chunk_nt<D>(x_out, c, o.x);
+            store_chunk_nt<D>(t_out, c, o.t);
+        },
+        [&](long n) {
+            float xp[D], tp[D];
+            load_point<D>(x, n, xp);
+            load_point<D>(v, n, tp);
+            euler_tangent_steps<Lib>(w, xp, tp, n_steps, dt);
+            store_point<D>(x_out, n, xp);
+            store_point<D>(t_out, n, tp);
+        });
 }
 
-template <class Lib>
+// Reverse sweep.  STACK = true: the forward pass parks the state (x_k, t_k) entering every step in a per-thread LDS
+// column (stack[(k * 2D + i) * BLOCK + tid]: consecutive lanes on consecutive banks), so the reverse pass is K library
+// evaluations; the launcher picks it while K * 2D * BLOCK floats fit beside the reduction's staging area (K <= 16 at
+// D = 2).  STACK = false: state k is recomputed from (x_0, t_0) -- K(K-1)/2 extra evaluations, no storage, any K.
+template <class Lib, bool STACK>
 __global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                               const float* __restrict__ g_x,
-                                                              const float* __restrict__ g_t, long N,
+                                                              const float* __restrict__ g_t, long N, bool vec,
                                                               const float* __restrict__ xi,
                                                               const float* __restrict__ mask, int n_steps, float dt,
                                                               float* __restrict__ grad_x, float* __restrict__ grad_v,
                                                               double* __restrict__ ws, Finish fin) {
-    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P;
+    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT;
+    extern __shared__ float stack[];
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
-    for (long n = tid; n < N; n += nthreads) {
-        float x0[D], t0[D], ax[D], at[D];
-        load_point<D>(x, n, x0);
-        load_point<D>(v, n, t0);
-        load_point<D>(g_x, n, ax);
-        load_point<D>(g_t, n, at);
-        for (int k = n_steps - 1; k >= 0; --k) {
+    const int tid = threadIdx.x;
+
+    // adjoints (ax, at) of (x_K, t_K) in, of (x_0, t_0) out
+    auto one = [&](const float (&x0)[D], const float (&t0)[D], float (&ax)[D], float (&at)[D]) {
+        if constexpr (STACK) {
             float xk[D], tk[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 xk[j] = x0[j];
                 tk[j] = t0[j];
             }
-            euler_tangent_steps<Lib>(w, xk, tk, k, dt);               // state entering step k
+            for (int k = 0; k < n_steps; ++k) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    stack[(k * 2 * D + j) * BLOCK + tid] = xk[j];
+                    stack[(k * 2 * D + D + j) * BLOCK + tid] = tk[j];
+                }
+                euler_tangent_steps<Lib>(w, xk, tk, 1, dt);
+            }
+        }
+        for (int k = n_steps - 1; k >= 0; --k) {
+            float xk[D], tk[D];
+            if constexpr (STACK) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    xk[j] = stack[(k * 2 * D + j) * BLOCK + tid];
+                    tk[j] = stack[(k * 2 * D + D + j) * BLOCK + tid];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    xk[j] = x0[j];
+                    tk[j] = t0[j];
+                }
+                euler_tangent_steps<Lib>(w, xk, tk, k, dt);               // state entering step k
+            }
             float th[P], dth[P], bar[P], dbar[P], bx[D], bv[D];
             Lib::eval_jvp(xk, tk, th, dth);
 #pragma unroll
@@ -1346,9 +1451,34 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __res
                 at[j] += bv[j];
             }
         }
-        store_point<D>(grad_x, n, ax);
-        store_point<D>(grad_v, n, at);
-    }
+    };
+    struct Ops {
+        float x[PPT][D], t[PPT][D], ax[PPT][D], at[PPT][D];
+    };
+    for_each_chunk2<D, BLOCK, Ops>(
+        N, vec,
+        [&](long c, Ops& o) {
+            load_chunk<D>(x, c, o.x);
+            load_chunk<D>(v, c, o.t);
+            load_chunk<D>(g_x, c, o.ax);
+            load_chunk<D>(g_t, c, o.at);
+        },
+        [&](long c, Ops& o) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) one(o.x[i], o.t[i], o.ax[i], o.at[i]);
+            store_chunk_nt<D>(grad_x, c, o.ax);
+            store_chunk_nt<D>(grad_v, c, o.at);
+        },
+        [&](long n) {
+            float x0[D], t0[D], ax[D], at[D];
+            load_point<D>(x, n, x0);
+            load_point<D>(v, n, t0);
+            load_point<D>(g_x, n, ax);
+            load_point<D>(g_t, n, at);
+            one(x0, t0, ax, at);
+            store_point<D>(grad_x, n, ax);
+            store_point<D>(grad_v, n, at);
+        });
     emit_partials<NACC>(acc, ws, fin);
 }
 
@@ -1599,7 +1729,8 @@ hipError_t launch_vjp(const float* x, const float* g, long n, const float* xi, c
     constexpr int NACC = 1 + Lib::D * Lib::P;
     double* part = ws + WS_HEADER_DOUBLES;
     const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
-    vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, xi, mask, grad_x, part, fin);
+    const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(g, n, Lib::D, 1) && (grad_x == nullptr || vec_ok(grad_x, n, Lib::D, 1));
+    vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, vec, xi, mask, grad_x, part, fin);
     SYMODE_LAUNCH_CHECK();
     return launch_finalize(fin, part, 1, gx, NACC, st);
 }
@@ -1608,8 +1739,10 @@ template <class Lib>
 hipError_t launch_forward_jvp(const float* x, const float* v, long n, const float* xi, const float* mask, float* out,
                               float* jv, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    const int g = grid_x_for(n, 1, 1);
-    forward_jvp_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, v, n, xi, mask, out, jv);
+    const int g = grid_x_for(n, 1, Chunk<Lib::D>::PPT);
+    const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(v, n, Lib::D, 1) && vec_ok(jv, n, Lib::D, 1) &&
+                     (out == nullptr || vec_ok(out, n, Lib::D, 1));
+    forward_jvp_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, v, n, vec, xi, mask, out, jv);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1621,7 +1754,9 @@ hipError_t launch_jvp_vjp(const float* x, const float* v, const float* g_out, co
     constexpr int NACC = 1 + Lib::D * Lib::P;
     double* part = ws + WS_HEADER_DOUBLES;
     const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
-    jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, part, fin);
+    const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(v, n, Lib::D, 1) && vec_ok(g_jv, n, Lib::D, 1) &&
+                     (g_out == nullptr || vec_ok(g_out, n, Lib::D, 1)) && vec_ok(grad_x, n, Lib::D, 1) && vec_ok(grad_v, n, Lib::D, 1);
+    jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, vec, xi, mask, grad_x, grad_v, part, fin);
     SYMODE_LAUNCH_CHECK();
     return launch_finalize(fin, part, 1, gx, NACC, st);
 }
@@ -1630,8 +1765,9 @@ template <class Lib>
 hipError_t launch_euler_jvp(const float* x, const float* v, long n, const float* xi, const float* mask, int n_steps,
                             float dt, float* x_out, float* t_out, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    const int g = grid_x_for(n, 1, 1);
-    euler_jvp_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, v, n, xi, mask, n_steps, dt, x_out, t_out);
+    const int g = grid_x_for(n, 1, Chunk<Lib::D>::PPT);
+    const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(v, n, Lib::D, 1) && vec_ok(x_out, n, Lib::D, 1) && vec_ok(t_out, n, Lib::D, 1);
+    euler_jvp_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, v, n, vec, xi, mask, n_steps, dt, x_out, t_out);
     SYMODE_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1643,8 +1779,19 @@ hipError_t launch_euler_jvp_vjp(const float* x, const float* v, const float* g_x
     constexpr int NACC = 1 + Lib::D * Lib::P;
     double* part = ws + WS_HEADER_DOUBLES;
     const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
-    euler_jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_x, g_t, n, xi, mask, n_steps, dt, grad_x,
-                                                                  grad_v, part, fin);
+    const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(v, n, Lib::D, 1) && vec_ok(g_x, n, Lib::D, 1) && vec_ok(g_t, n, Lib::D, 1) &&
+                     vec_ok(grad_x, n, Lib::D, 1) && vec_ok(grad_v, n, Lib::D, 1);
+    // per-thread LDS column for the K states while it fits (40 KB at K = 10, D = 2, next to 17 KB of reduction staging:
+    // two workgroups per CU); SYMODE_EULER_STACK=0 forces the recompute form (A/B and the parity test)
+    const size_t stack_bytes = (size_t)n_steps * 2 * Lib::D * BLOCK * sizeof(float);
+    const char* se = getenv("SYMODE_EULER_STACK");
+    const bool use_stack = n_steps > 1 && stack_bytes <= 64 * 1024 && !(se && se[0] == '0');
+    if (use_stack)
+        euler_jvp_vjp_kernel<Lib, true><<<dim3(gx, 1), dim3(BLOCK), stack_bytes, st>>>(x, v, g_x, g_t, n, vec, xi, mask, n_steps, dt,
+                                                                                      grad_x, grad_v, part, fin);
+    else
+        euler_jvp_vjp_kernel<Lib, false><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_x, g_t, n, vec, xi, mask, n_steps, dt, grad_x,
+                                                                             grad_v, part, fin);
     SYMODE_LAUNCH_CHECK();
     return launch_finalize(fin, part, 1, gx, NACC, st);
 }

@@ -158,6 +158,23 @@ __device__ __forceinline__ void store_chunk(float* __restrict__ a, long c, const
     for (int i = 0; i < NV; ++i) q[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
 }
 
+// Same, as non-temporal stores: outputs of the streaming maps are written once and not read back by the kernel.
+template <int D>
+__device__ __forceinline__ void store_chunk_nt(float* __restrict__ a, long c, const float (&p)[Chunk<D>::PPT][D]) {
+    if constexpr (D == 3) {
+        store_chunk<D>(a, c, p);                                   // coalesced tile stores through the wave's LDS slab
+    } else {
+        constexpr int NV = Chunk<D>::NV;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v* q = reinterpret_cast<f4v*>(a) + c * NV;
+        float f[NV * 4];
+#pragma unroll
+        for (int i = 0; i < NV * 4; ++i) f[i] = p[i / D][i % D];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) __builtin_nontemporal_store(f4v{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]}, q + i);
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void load_point(const float* __restrict__ a, long n, float (&p)[D]) {
 #pragma unroll
@@ -188,6 +205,37 @@ __device__ __forceinline__ void for_each_point(long N, bool vec, ChunkBody chunk
             chunk_body(c + nthreads);
         }
         if (c < nchunks) chunk_body(c);
+        const long n = nchunks * PPT + tid;
+        if (n < N) point_body(n);
+    } else {
+        for (long n = tid; n < N; n += nthreads) point_body(n);
+    }
+}
+
+// Two-chunk software pipeline over one (N, D) problem: per step the operands of chunks c and c + nthreads are
+// requested (load(c, ops): 16-byte non-temporal vectors through load_chunk) before either chunk is computed
+// (compute(c, ops)), so a lane keeps two chunks of every operand in flight; ragged tails and unaligned bases go
+// point by point.  Ops is the caller's bundle of per-chunk operand registers.
+template <int D, int BLOCK, class Ops, typename Load, typename Compute, typename PointBody>
+__device__ __forceinline__ void for_each_chunk2(long N, bool vec, Load load, Compute compute, PointBody point_body) {
+    constexpr int PPT = Chunk<D>::PPT;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
+    const long nthreads = (long)gridDim.x * BLOCK;
+    if (vec) {
+        const long nchunks = N / PPT;
+        long c = tid;
+        for (; c + nthreads < nchunks; c += 2 * nthreads) {
+            Ops a, b;
+            load(c, a);
+            load(c + nthreads, b);
+            compute(c, a);
+            compute(c + nthreads, b);
+        }
+        if (c < nchunks) {
+            Ops a;
+            load(c, a);
+            compute(c, a);
+        }
         const long n = nchunks * PPT + tid;
         if (n < N) point_body(n);
     } else {

@@ -544,3 +544,37 @@ def test_bench_starts_its_own_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["ranks_observed"] == 2 and rec["warmup"] == 1 and rec["steps"] == 3
     assert rec["metric"].endswith("sym-reg") and len(rec["roofline_legs"]) == 2 and rec["value"] > 0
+
+
+@pytest.mark.parametrize("d,order,fl,K,n", [(2, 2, 2, 10, 20000), (2, 3, 0, 3, 4097), (3, 2, 0, 5, 3001), (1, 4, 1, 16, 1000), (2, 5, 0, 20, 2500),
+                                            (4, 2, 0, 4, 999)])
+def test_euler_reverse_sweep_state_stack_equals_recompute(eng, d, order, fl, K, n):
+    """euler_jvp_vjp keeps the K step states in an LDS column (K <= 16 at d = 2) or recomputes them (larger K,
+    SYMODE_EULER_STACK=0): the same adjoints either way, and both match torch autograd through the stepwise flow."""
+    torch.manual_seed(K * 7 + n)
+    p = eng.lib_size(d, order, fl)
+    x, v, gx_, gt_ = ((torch.randn(n, d) * 0.4).cuda() for _ in range(4))
+    xi = (torch.randn(d, p) * 0.2).cuda()
+    mask = (torch.rand(d, p) > 0.2).float().cuda()
+    with _env(SYMODE_EULER_STACK=0):
+        a = eng.euler_jvp_vjp(x, v, gx_, gt_, xi, mask, order, fl, K, 0.01)
+    with _env(SYMODE_EULER_STACK=1):
+        b = eng.euler_jvp_vjp(x, v, gx_, gt_, xi, mask, order, fl, K, 0.01)
+    for u, w_, nm in zip(a, b, ("grad_x", "grad_v", "grad_xi")):
+        assert_close_scaled(w_.cpu(), u.cpu(), 2e-6, f"stack vs recompute {nm}")
+    # reference: fp64 autograd through K explicit steps of the oracle's forward
+    X = x.cpu().double().requires_grad_(True)
+    V = v.cpu().double().requires_grad_(True)
+    W = xi.cpu().double().requires_grad_(True)
+    M = mask.cpu().double()
+    f = lambda a_: O.forward(a_, W, M, order, bool(fl & 1), bool(fl & 2))  # noqa: E731
+    xs, ts = X, V
+    for _ in range(K):
+        h, jt = torch.autograd.functional.jvp(f, xs, ts, create_graph=True)
+        xs, ts = xs + 0.01 * h, ts + 0.01 * jt
+    ((xs * gx_.cpu().double()).sum() + (ts * gt_.cpu().double()).sum()).backward()
+    for got, want, nm in zip(b, (X.grad, V.grad, W.grad * M), ("grad_x", "grad_v", "grad_xi")):
+        assert_close_scaled(got.cpu(), want, 3e-5, f"euler_jvp_vjp {nm} vs fp64 autograd")
+    xo, to = eng.euler_jvp(x, v, xi, mask, order, fl, K, 0.01)
+    assert_close_scaled(xo.cpu(), xs.detach(), 1e-5, "euler_jvp x_K")
+    assert_close_scaled(to.cpu(), ts.detach(), 1e-5, "euler_jvp t_K")

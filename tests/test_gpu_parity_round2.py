@@ -134,12 +134,14 @@ def _oracle_run(g, tag):
 @pytest.mark.parametrize("tag", ["dosc_sindy", "dosc_esindy", "selkov_sindy"])
 def test_hip_closure_along_the_recorded_lbfgs_trajectory(S, golden, tag):
     """Every closure point (Xi, mask) the pinned oracle run visits -- from the random start to the converged sparse
-    model -- evaluated by ONE batched launch of the fused kernel: loss within rtol 1e-5 of the oracle's, gradient within
-    1e-5 of the size of its summands, 2/(N d) sum_n |r_nj| |Theta_nk| (near the optimum the gradient itself is the
-    cancellation residue of those summands, so its own magnitude is no yardstick; where it is not small it is also
-    checked against its max-norm at 2e-5).  This is what licenses the looser end-of-run coefficient tolerance of the
-    trainer tests: both runs follow the same map, evaluated to 1e-5, until L-BFGS's own stopping ball (update norm
-    < 1e-3, train.py:705)."""
+    model -- evaluated by ONE batched launch of the fused kernel: loss within rtol 1e-5 of the oracle's; gradient within
+    1e-5 of the magnitude of the operands it is formed from, 2/(N d) sum_n (|Theta_n| |w_j| + |dx_nj|) |Theta_nk| --
+    the forward-error yardstick of an fp32 evaluation: at the end of a noise-free fit the residual is 1e-4 of its
+    operands, so the gradient is a cancellation residue whose own size says nothing (the oracle's fp32 gradient is itself
+    1.5e-4 of its summands away from the fp64 value there, and 2e-7 on this yardstick) -- and, wherever the residual is
+    not at the rounding floor (loss > 1e-3 mean(dx^2)), within 2e-5 of the gradient's own max-norm.  This is what
+    licenses the looser end-of-run coefficient tolerance of the trainer tests: both runs follow the same map, evaluated
+    to 1e-5, until L-BFGS's own stopping ball (update norm < 1e-3, train.py:705)."""
     g = golden("f4_lbfgs")
     reg, hist, x, dx, order = _oracle_run(g, tag)
     trace = reg.trace
@@ -153,20 +155,21 @@ def test_hip_closure_along_the_recorded_lbfgs_trajectory(S, golden, tag):
     loss, grad = eng.loss_grad(X, DX, Xi, M, order)
     loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
     worst_l = worst_g = worst_rel = 0.0
-    th = O.theta(x, order).double()
+    th = O.theta(x, order).double().abs()
+    dx_scale = float((dx.double() ** 2).mean())
     for k, (a, b) in enumerate(trace):
         wl, wg = O.mse_loss_and_grad(x, dx, a, b, order)
         wl, wg = wl.item(), wg.numpy()
-        r = (th @ (a * b).double().T - dx.double()).abs()
-        summands = (2.0 / r.numel()) * (r.T @ th.abs()).numpy()                 # (d, p): size of what each entry adds up
+        operands = th @ (a * b).double().abs().T + dx.double().abs()            # (N, d): what the residual is the difference of
+        yard = (2.0 / operands.numel()) * (operands.T @ th).numpy()             # (d, p)
         # losses at the 1e-9 floor of a noise-free fit are sums of squared fp32 rounding errors of the residual itself
         worst_l = max(worst_l, abs(loss[k] - wl) / max(abs(wl), 1e-7))
         live = b.numpy() > 0
-        worst_g = max(worst_g, (np.abs(grad[k] - wg)[live] / summands[live]).max())
-        if np.abs(wg).max() > 1e-2 * summands[live].max():                      # a gradient that is not cancellation residue
+        worst_g = max(worst_g, (np.abs(grad[k] - wg)[live] / yard[live]).max())
+        if wl > 1e-3 * dx_scale:                                                # residual well above the rounding floor
             worst_rel = max(worst_rel, np.abs(grad[k] - wg).max() / np.abs(wg).max())
-    print(f"{tag}: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad err vs summands {worst_g:.2e}, "
-          f"vs max-norm (non-degenerate points) {worst_rel:.2e}")
+    print(f"{tag}: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad err vs operand magnitude {worst_g:.2e}, "
+          f"vs max-norm (points off the rounding floor) {worst_rel:.2e}")
     assert worst_l <= 1e-5, worst_l
     assert worst_g <= 1e-5, worst_g
     assert worst_rel <= 2e-5, worst_rel
