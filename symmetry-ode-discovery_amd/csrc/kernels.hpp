@@ -913,7 +913,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
             for (int j = 0; j < D; ++j)
 #pragma unroll
                 for (int k = 0; k < P; ++k)
-                    acc[1 + j * P + k] += u[j] * dth[k] - ltu[j] * th[k];
+                    acc[1 + j * P + k] = fmaf(u[j], dth[k], fmaf(-ltu[j], th[k], acc[1 + j * P + k]));
         }
     };
     for_each_point<D, BLOCK>(

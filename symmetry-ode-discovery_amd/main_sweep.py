@@ -55,8 +55,9 @@ def _write_results(args, seeds, Xi, mask, truth):
                  mse_all=np.mean(mse))
 
 
-def main(argv=None, engine=None, backend='nccl'):
-    """``engine`` / ``backend`` exist for the CPU rehearsal of the multi-rank path in tests (gloo + the test engine)."""
+def main(argv=None, engine=None, backend='nccl', one_gpu=False):
+    """``engine`` / ``backend`` exist for the CPU rehearsal of the multi-rank path in tests (gloo + the test engine);
+    ``one_gpu``: every rank uses cuda:0 (rehearsal of the HIP path with several ranks on a one-GPU box, gloo collectives)."""
     argv = list(sys.argv[1:] if argv is None else argv)
     n_seeds = _pop(argv, '--n_seeds', 50, int)
     method = _pop(argv, '--method', 'lbfgs', str)
@@ -68,7 +69,7 @@ def main(argv=None, engine=None, backend='nccl'):
         if str(args['device']) == 'cpu':
             raise SystemExit('symode_amd runs the SINDy path on the GPU only (no CPU fallback): a HIP device is required')
         if world > 1:
-            local = int(os.environ.get('LOCAL_RANK', '0'))
+            local = 0 if one_gpu else int(os.environ.get('LOCAL_RANK', '0'))
             torch.cuda.set_device(local)
             args['device'] = torch.device('cuda', local)
     if args['sindy_optimizer'] != 'lbfgs' or args['use_latent'] or args['w_sym_reg'] > 0:
@@ -86,14 +87,18 @@ def main(argv=None, engine=None, backend='nccl'):
             train_dataset, _, args = get_dataset(args)
     else:
         train_dataset, _, args = get_dataset(args)
-    # this rank's block of whole trajectories (dataset.py:193-194 flattens (n_ics, n_steps, d) row-major)
-    n_ics, n_steps = train_dataset.n_ics, train_dataset.n_steps
-    lo, hi = rank * n_ics // world, (rank + 1) * n_ics // world
-    x_all = train_dataset.x[lo * n_steps:hi * n_steps].to(dev)
-    dx_all = train_dataset.dx[lo * n_steps:hi * n_steps].to(dev)
-    n_local = x_all.shape[0]
-    m = int(n_local * args['lbfgs_subsample'])
+    # Every seed draws ONE subsample of the whole flattened data set (main.py:36-38: the first batch of a shuffled loader),
+    # seeded by the seed alone; rank r works on rows [r m / W, (r+1) m / W) of that draw.  The union over the ranks is
+    # the single-process subsample whatever the world size, so an N-rank run fits the same problems as a 1-rank run and
+    # differs from it by summation order only.  (The data sets of the reference are a few MB: every rank keeps all of
+    # x, dx resident and gathers its rows; the COMPUTE is what is sharded.)
+    x_all, dx_all = train_dataset.x.to(dev), train_dataset.dx.to(dev)
+    n_all = x_all.shape[0]
+    m = int(n_all * args['lbfgs_subsample'])
+    m -= m % world                                       # equal shards: every rank normalises by the same global count
+    lo, hi = rank * m // world, (rank + 1) * m // world
     seeds = list(range(args['seed'], args['seed'] + n_seeds))
+    gens = [torch.Generator().manual_seed(s) for s in seeds]
 
     truth = sindy_truth[args['task']]
 
@@ -105,8 +110,9 @@ def main(argv=None, engine=None, backend='nccl'):
     if method == 'stlsq':
         if args['eq_constraint']:
             raise SystemExit('--method stlsq sweeps the unconstrained library (use --method lbfgs for EquivSINDy-c)')
+        idx = torch.stack([torch.randperm(n_all, generator=g)[:m][lo:hi] for g in gens])
         sw = SeedSweepSTLSQ(x_all, dx_all, args['poly_order'], args['include_sine'], args['include_exp'], n_seeds=n_seeds,
-                            subsample=args['lbfgs_subsample'], seed0=args['seed'], group=group, engine=engine)
+                            subsample=args['lbfgs_subsample'], seed0=args['seed'], group=group, engine=engine, idx=idx)
         Xi, mask, passes = sw.solve(args['w_sindy_reg'], args['threshold'], max_iter=max(1, args['num_epochs']),
                                     lstsq_driver=args.get('lstsq_driver'))
         if rank == 0:
@@ -126,15 +132,14 @@ def main(argv=None, engine=None, backend='nccl'):
         args['L_list'] = [L[:rd, :rd].detach().cpu() for L in L_list]
     template = SINDyRegression(**args, **({'engine': engine} if engine is not None else {})).to(dev)
     inits, xs, dxs = [], [], []
-    for s in seeds:
-        g = torch.Generator().manual_seed(s)
+    for s, g in zip(seeds, gens):
         if template.constraint:
             beta = torch.randn(template.Q.shape[1], generator=g)
             const = torch.randn(template.latent_dim, generator=g)
             inits.append(torch.cat([beta, const]))
         else:
             inits.append(torch.randn(template.latent_dim * template.get_term_num(), generator=g))
-        rows = torch.randperm(n_local, generator=g)[:m].to(dev)
+        rows = torch.randperm(n_all, generator=g)[:m][lo:hi].to(dev)
         xs.append(x_all[rows])
         dxs.append(dx_all[rows])
     X, DX = torch.stack(xs).contiguous(), torch.stack(dxs).contiguous()

@@ -20,8 +20,10 @@ from .sindy import NEAR_THRESHOLD_BAND, near_threshold_cases, stlsq_solve_from_g
 
 class SeedSweepSTLSQ:
     def __init__(self, x, dx, poly_order, include_sine=False, include_exp=False, n_seeds=64, subsample=0.5, seed0=0,
-                 group=None, engine=None):
-        """x, dx: this rank's shard (N_local, d) of the flattened data set (dataset.py:193-194)."""
+                 group=None, engine=None, idx=None):
+        """x, dx: (N_local, d) rows of the flattened data set (dataset.py:193-194) this rank gathers from.
+        ``idx`` (S, m_local) int32: the rows of x this rank contributes to each seed's subsample; by default every
+        (seed, rank) draws its own seeded permutation of the rank's shard."""
         assert x.dim() == 2 and x.shape == dx.shape
         self.engine = engine or get_engine()
         self.x, self.dx = x.contiguous(), dx.contiguous()
@@ -30,14 +32,19 @@ class SeedSweepSTLSQ:
         self.p = self.engine.lib_size(self.d, poly_order, self.flags)
         self.S = n_seeds
         self.group = group
-        rank = dist.get_rank(group) if group is not None else 0
-        m = max(1, int(self.n_local * subsample))
-        rows = []
-        for s in range(n_seeds):                      # seeded permutation per (seed, rank): reproducible subsets
-            g = torch.Generator().manual_seed(1_000_003 * (seed0 + s) + rank)
-            rows.append(torch.randperm(self.n_local, generator=g)[:m])
-        self.idx = torch.stack(rows).to(torch.int32).to(x.device)
-        self.m_local = m
+        if idx is not None:
+            assert idx.dim() == 2 and idx.shape[0] == n_seeds
+            self.idx = idx.to(torch.int32).to(x.device).contiguous()
+            self.m_local = idx.shape[1]
+        else:
+            rank = dist.get_rank(group) if group is not None else 0
+            m = max(1, int(self.n_local * subsample))
+            rows = []
+            for s in range(n_seeds):                      # seeded permutation per (seed, rank): reproducible subsets
+                g = torch.Generator().manual_seed(1_000_003 * (seed0 + s) + rank)
+                rows.append(torch.randperm(self.n_local, generator=g)[:m])
+            self.idx = torch.stack(rows).to(torch.int32).to(x.device)
+            self.m_local = m
         self._gram = None
 
     def grams(self):
