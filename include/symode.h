@@ -104,6 +104,17 @@ int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const in
                            int order, int flags, double* gram_out, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* Weak SINDy: the contraction of the test functions with the library, fused with the library build (fp64 MFMA, Theta
+ * never written).  x (n_t, d): ONE trajectory on a uniform time grid; V, V_drv (n_test, n_t) fp32 row-major: the test
+ * functions and their derivatives times dt (sindy.py:346-347).  out: fp64 row-major (R, C) with R = 16*ceil(2 n_test/16),
+ * C = 16*ceil((p+d)/16):
+ *     out[k, j]            = sum_t V[k, t] Theta_j(x_t)          k < n_test, j < p        (= G, sindy.py:363)
+ *     out[n_test + k, p+i] = -sum_t V_drv[k, t] x_i(t)           k < n_test, i < d        (= b, sindy.py:364)
+ * (the other entries are by-products of the 16x16 tiles).  n_test <= 128.
+ * replaces: self.V @ self.regressor.eval_Theta_at(x) and -self.V_drv @ x, sindy.py:362-364. */
+int symode_weak_gram(const float* x, long n_t, int d, int order, int flags, const float* V, const float* V_drv, int n_test,
+                     double* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* S1, linear-latent symmetry regulariser (train.py:502-507 with the intended [1]):
  *   loss = sum_v sum_n || Xi_m J_Theta(z_n)(L_v z_n) - L_v Xi_m Theta(z_n) ||^2,
  *   grad (d, p) = dloss/dxi (masked).  L: (n_gen, d, d). */

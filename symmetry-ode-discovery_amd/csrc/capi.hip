@@ -227,6 +227,22 @@ int symode_symreg_reversed(const float* x, const float* gx_, const float* jgx, i
                                           loss_out, grad_out, workspace, workspace_bytes, stream);
 }
 
+int symode_weak_gram(const float* x, long n_t, int d, int order, int flags, const float* V, const float* V_drv, int n_test,
+                     double* out, void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n_t < 1 || n_test < 1 || n_test > 128) return SYMODE_E_BADSIZE;
+    if (!x || !V || !V_drv || !out) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(V, 4) || misaligned(V_drv, 4) || misaligned(out, 8)) return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(1, n_t);
+    const int RT = (2 * n_test + 15) / 16, CT = (ops->p + ops->d + 15) / 16;
+    long gx = (n_t + 255) / 256;                                   // a workgroup = 4 waves x 64 time points per step
+    if (gx > 64) gx = 64;
+    const size_t avail = workspace_bytes / sizeof(double) - (size_t)WS_HEADER_DOUBLES;
+    while (gx > 1 && (size_t)gx * RT * CT * 256 > avail) gx /= 2;
+    if ((size_t)gx * RT * CT * 256 > avail) return SYMODE_E_WORKSPACE;
+    return (int)ops->weak_gram(x, n_t, V, V_drv, n_test, out, (double*)workspace, (int)gx, (hipStream_t)stream);
+}
+
 int symode_vjp(const float* x, const float* g, long n, int d, int order, int flags, const float* xi, const float* mask,
                float* grad_x, float* grad_xi, void* workspace, size_t workspace_bytes, void* stream) {
     SYMODE_GET_OPS();

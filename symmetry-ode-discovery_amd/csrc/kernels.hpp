@@ -55,6 +55,8 @@ struct LibOps {
     hipError_t (*euler_jvp_vjp)(const float* x, const float* v, const float* g_x, const float* g_t, long n, const float* xi,
                                 const float* mask, int n_steps, float dt, float* grad_x, float* grad_v, float* grad_xi,
                                 double* ws, int gx, hipStream_t st);
+    hipError_t (*weak_gram)(const float* x, long T, const float* V, const float* Vd, int K, double* out, double* ws, int gx,
+                            hipStream_t st);
 };
 
 // ---------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #pragma once
 #include "gram.hpp"
 #include "kernels.hpp"
+#include "weak.hpp"
 
 namespace symode {
 
@@ -25,7 +26,8 @@ constexpr LibOps make_ops() {
                   &launch_jvp_vjp<Lib>,
                   &launch_rk4_traj<Lib>,
                   &launch_euler_jvp<Lib>,
-                  &launch_euler_jvp_vjp<Lib>};
+                  &launch_euler_jvp_vjp<Lib>,
+                  &launch_weak_gram<Lib>};
 }
 
 #define SYMODE_OPS_ALL_FLAGS(D, O) make_ops<D, O, 0>(), make_ops<D, O, 1>(), make_ops<D, O, 2>(), make_ops<D, O, 3>()

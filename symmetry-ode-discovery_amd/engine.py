@@ -44,6 +44,8 @@ _SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_symreg_reversed_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_long, c_int, c_int, c_int, c_void_p,
                                                c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "symode_weak_gram": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                 c_void_p]),
     "symode_vjp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
     "symode_forward_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -324,6 +326,21 @@ class HipEngine:
             return loss.reshape(-1)[0], grad.reshape(d, p)
         return loss, grad
 
+
+    def weak_gram(self, x, V, V_drv, order, flags=0):
+        """Weak-SINDy contraction: x (T, d) one trajectory, V / V_drv (K, T) -> (G = V Theta(x) (K, p), b = -V_drv x (K, d)), fp64."""
+        x, V, V_drv = self._dev(x, "x"), self._dev(V, "V"), self._dev(V_drv, "V_drv")
+        if x.dim() != 2 or V.dim() != 2 or V.shape != V_drv.shape or V.shape[1] != x.shape[0]:
+            raise SymodeError(f"weak_gram expects x (T, d) and V, V_drv (K, T); got {tuple(x.shape)}, {tuple(V.shape)}, {tuple(V_drv.shape)}")
+        T, d = x.shape
+        K = V.shape[0]
+        p = self.lib_size(d, order, flags)
+        R, C = 16 * ((2 * K + 15) // 16), 16 * ((p + d + 15) // 16)
+        out = torch.empty(R, C, dtype=torch.float64, device=x.device)
+        ws = self.workspace(x.device, d, order, flags, 1, T)
+        self._check(self.lib.symode_weak_gram(self._ptr(x), T, d, order, flags, self._ptr(V), self._ptr(V_drv), K, self._ptr(out),
+                                              self._ptr(ws), ws.numel() * 8, self._stream(x)), "symode_weak_gram")
+        return out[:K, :p], out[K:2 * K, p:p + d]
 
     def vjp(self, x, g, xi, mask, order, flags=0, need_grad_x=True):
         """Reverse mode of forward: returns (grad_x (N, d) or None, grad_xi (d, p))."""

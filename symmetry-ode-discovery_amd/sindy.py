@@ -412,9 +412,10 @@ class WSINDyWrapper():
     test functions g_k(t) = sqrt(2/T) sin(k pi t / T), V = dt g, V' = dt g'; G = V Theta(x), b = -V' x;
     solve  min || [V^T G; sqrt(gamma) I] w - [V^T b; 0] ||  on the current support, then threshold.
 
-    Theta(x) comes from the HIP library kernel; the (n_test x T)(T x p) contractions are plain
-    library GEMMs (torch/hipBLAS, fp64); the (p x p) normal system is solved on the host with
-    the same LAPACK semantics as solve_SINDy_one_step.
+    The data pass is ONE fused launch (symode_weak_gram: Theta built in registers, G = V Theta(x) and b = -V' x
+    accumulated by the fp64 matrix cores, Theta never written).  The reference's system  [V^T G; sqrt(gamma) I] w =
+    [V^T b; 0]  has the normal equations  G^T (V V^T) G + gamma I  and  G^T (V V^T) b  -- the (K, K) matrix V V^T does not
+    depend on the data and is formed once -- which the host solves with the same LAPACK semantics as solve_SINDy_one_step.
     """
 
     def __init__(self, regressor, t, t_max, num_test_funcs=50, test_func_family='trig', device='cuda', **kwargs):
@@ -427,24 +428,27 @@ class WSINDyWrapper():
         amp = (2 / t_max) ** 0.5
         g = amp * torch.sin(k * torch.pi * self.t / t_max)
         g_drv = amp * k * np.pi / t_max * torch.cos(k * np.pi * self.t / t_max)
-        self.V = self.dt * g                                                      # sindy.py:346-347
-        self.V_drv = self.dt * g_drv
+        self.V = (self.dt * g).contiguous()                                       # sindy.py:346-347
+        self.V_drv = (self.dt * g_drv).contiguous()
+        Vh = self.V.double().cpu().numpy()
+        self._VVt = Vh @ Vh.T                                                     # (K, K) fp64, data independent
 
     def solve(self, x, w_sindy_reg, st_threshold, **kwargs):
         reg = self.regressor
         d = reg.latent_dim
         with torch.no_grad():
-            theta = reg.eval_Theta_at(x)                                          # HIP
-            V, Vd = self.V.double(), self.V_drv.double()
-            G = V @ theta.double()                                                # (K, p)
-            b = -Vd @ x.double()                                                  # (K, d)
-            A = V.T @ G                                                           # rows of the reference's G_aug
-            rhs = V.T @ b
+            if hasattr(reg.engine, 'weak_gram'):
+                G, b = reg.engine.weak_gram(x.reshape(-1, d), self.V, self.V_drv, reg.poly_order, reg.flags)   # ONE fused launch
+                G, b = G.cpu().numpy(), b.cpu().numpy()                           # (K, p), (K, d) fp64
+            else:                                                                 # engines without the fused entry (test double)
+                G = (self.V.double() @ reg.eval_Theta_at(x).double()).cpu().numpy()
+                b = (-self.V_drv.double() @ x.double()).cpu().numpy()
             p = G.shape[1]
-            Gn = (A.T @ A + float(w_sindy_reg) * torch.eye(p, dtype=torch.float64, device=A.device)).cpu().numpy()
-            Cn = (A.T @ rhs).cpu().numpy()                                        # (p, d)
-            bb = float((rhs * rhs).sum())
-            m_rows = A.shape[0] + p
+            MG = self._VVt @ G                                                    # A^T A = G^T (V V^T) G with A = V^T G
+            Gn = G.T @ MG + float(w_sindy_reg) * np.eye(p)
+            Cn = MG.T @ b                                                         # (p, d) = A^T (V^T b)
+            bb = float(np.sum(b * (self._VVt @ b)))
+            m_rows = self.V.shape[1] + p
             mask = (reg.mask > 0.0).cpu().numpy()
             driver = kwargs.get('lstsq_driver', reg.lstsq_driver)
             prev_mask = reg.mask.clone()

@@ -578,3 +578,20 @@ def test_euler_reverse_sweep_state_stack_equals_recompute(eng, d, order, fl, K, 
     xo, to = eng.euler_jvp(x, v, xi, mask, order, fl, K, 0.01)
     assert_close_scaled(xo.cpu(), xs.detach(), 1e-5, "euler_jvp x_K")
     assert_close_scaled(to.cpu(), ts.detach(), 1e-5, "euler_jvp t_K")
+
+
+@pytest.mark.parametrize("T,K,d,order,fl", [(2000, 50, 2, 3, 0), (777, 50, 2, 2, 2), (8000, 50, 2, 5, 0), (300, 7, 3, 2, 1), (64, 128, 1, 4, 0),
+                                            (1000, 20, 4, 3, 0)])
+def test_weak_gram_fused_contraction(eng, T, K, d, order, fl):
+    """symode_weak_gram: G = V Theta(x), b = -V' x accumulated by the fp64 matrix cores vs an fp64 host product of the
+    same fp32 library and test functions (exact products, fp64 sums: 1e-12 like the Gram)."""
+    torch.manual_seed(T + K)
+    x = torch.randn(T, d) * 0.6
+    V, Vd = torch.randn(K, T) * 0.1, torch.randn(K, T)
+    G, b = eng.weak_gram(x.cuda(), V.cuda(), Vd.cuda(), order, fl)
+    th = O.theta(x, order, bool(fl & 1), bool(fl & 2))
+    th_gpu = eng.theta(x.cuda(), order, fl).cpu()                  # sin / exp columns: the device's own fp32 values
+    want_G, want_b = V.double() @ th_gpu.double(), -(Vd.double() @ x.double())
+    assert G.shape == (K, th.shape[1]) and b.shape == (K, d)
+    assert torch.allclose(G.cpu(), want_G, rtol=1e-12, atol=1e-12 * want_G.abs().max().item())
+    assert torch.allclose(b.cpu(), want_b, rtol=1e-12, atol=1e-12 * want_b.abs().max().item())

@@ -140,7 +140,8 @@ def test_train_sindy_and_wsindy_on_gpu(S, golden):
     for wm, wx, wc in zip(w["masks"], w["xis"], w["conv"]):
         res, c = wr.solve(xw, 0.0, 0.05)
         assert np.array_equal(r.mask.cpu().numpy(), wm) and bool(c) == bool(wc)
-        assert np.allclose(r.Xi.detach().cpu().numpy(), wx, rtol=1e-3, atol=1e-3 * np.abs(wx).max())
+        # fused fp64 contraction (symode_weak_gram): the reference's own fp32 GEMMs are the remaining difference
+        assert np.allclose(r.Xi.detach().cpu().numpy(), wx, rtol=1e-5, atol=1e-5 * np.abs(wx).max()), np.abs(r.Xi.detach().cpu().numpy() - wx).max() / np.abs(wx).max()
 
 
 def _train_kwargs(**over):
