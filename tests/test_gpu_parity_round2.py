@@ -138,8 +138,9 @@ def test_hip_closure_along_the_recorded_lbfgs_trajectory(S, golden, tag):
     1e-5 of the magnitude of the operands it is formed from, 2/(N d) sum_n (|Theta_n| |w_j| + |dx_nj|) |Theta_nk| --
     the forward-error yardstick of an fp32 evaluation: at the end of a noise-free fit the residual is 1e-4 of its
     operands, so the gradient is a cancellation residue whose own size says nothing (the oracle's fp32 gradient is itself
-    1.5e-4 of its summands away from the fp64 value there, and 2e-7 on this yardstick) -- and, wherever the residual is
-    not at the rounding floor (loss > 1e-3 mean(dx^2)), within 2e-5 of the gradient's own max-norm.  This is what
+    1.5e-4 of its summands away from the fp64 value there, and 2e-7 on this yardstick) -- and, wherever the gradient
+    loses less than one digit to that cancellation (max |g| >= 0.1 of the yardstick), within 2e-5 of its own max-norm.
+    This is what
     licenses the looser end-of-run coefficient tolerance of the trainer tests: both runs follow the same map, evaluated
     to 1e-5, until L-BFGS's own stopping ball (update norm < 1e-3, train.py:705)."""
     g = golden("f4_lbfgs")
@@ -156,7 +157,6 @@ def test_hip_closure_along_the_recorded_lbfgs_trajectory(S, golden, tag):
     loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
     worst_l = worst_g = worst_rel = 0.0
     th = O.theta(x, order).double().abs()
-    dx_scale = float((dx.double() ** 2).mean())
     for k, (a, b) in enumerate(trace):
         wl, wg = O.mse_loss_and_grad(x, dx, a, b, order)
         wl, wg = wl.item(), wg.numpy()
@@ -166,10 +166,10 @@ def test_hip_closure_along_the_recorded_lbfgs_trajectory(S, golden, tag):
         worst_l = max(worst_l, abs(loss[k] - wl) / max(abs(wl), 1e-7))
         live = b.numpy() > 0
         worst_g = max(worst_g, (np.abs(grad[k] - wg)[live] / yard[live]).max())
-        if wl > 1e-3 * dx_scale:                                                # residual well above the rounding floor
+        if np.abs(wg).max() >= 0.1 * yard[live].max():                          # less than one digit lost to cancellation
             worst_rel = max(worst_rel, np.abs(grad[k] - wg).max() / np.abs(wg).max())
     print(f"{tag}: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad err vs operand magnitude {worst_g:.2e}, "
-          f"vs max-norm (points off the rounding floor) {worst_rel:.2e}")
+          f"vs max-norm (points with little cancellation) {worst_rel:.2e}")
     assert worst_l <= 1e-5, worst_l
     assert worst_g <= 1e-5, worst_g
     assert worst_rel <= 2e-5, worst_rel

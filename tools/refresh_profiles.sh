@@ -1,18 +1,33 @@
 #!/bin/bash
 # Re-measure everything under profiles/ on the GPU box (run through gpurun from the repo root):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh'
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r02'
 # Raw traces go to /tmp on the box; only the condensed summaries land in gpurun_out/ (copy them to profiles/).
 set -o pipefail
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd "$R" && python bench.py > gpurun_out/r01_bench_n1.json 2>/dev/null
+O="$R/gpurun_out"
+mkdir -p "$O"
+cd "$R" && python bench.py > "$O/${TAG}_bench_n1.json" 2> "$O/${TAG}_bench_n1.err" && echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 "$R/bench.py" --steps 20 --warmup 3 --profile > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 "$R/bench.py" --steps 5 --warmup 1 --profile > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 "$R/bench.py" --steps 5 --warmup 1 --profile > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ops -- python3 "$R/tests/perf/ops_table.py" > /dev/null 2>&1
+# per-kernel durations of the bench step (same command, profiling mode: only the K batched steps)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 "$R/bench.py" --steps 20 --warmup 3 --profile > /dev/null 2>&1 && echo "trace done"
+# HBM traffic: separate PMC passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile > /dev/null 2>&1 && echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile > /dev/null 2>&1 && echo "write done"
+# every streaming entry point at 2^26 points under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ops -- python3 "$R/tools/kbench.py" --table --S 1 --N 67108864 --libs 3:0,2:2 --reps 3 > "$O/${TAG}_ops_roofline.md" 2>/dev/null && echo "ops done"
+# VALU counters of the arithmetic-bound kernels, MFMA counters of the Gram
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_valu -- python3 "$R/tools/kbench.py" --table --S 1 --N 67108864 --libs 3:0 --reps 1 --only euler_jvp euler_jvp_vjp odeint odeint_rk4 symreg_linear loss_grad symreg_reversed > /dev/null 2>&1 && echo "valu done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma3 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 3 --reps 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 3 > /dev/null 2>&1 && echo "mfma done"
 cd "$R"
-python tools/rocprof_summary.py /tmp/prof_bench > gpurun_out/r01_bench_kernel_stats.txt
-python tools/rocprof_summary.py /tmp/prof_ops > gpurun_out/r01_ops_kernel_stats.txt
-python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write loss_grad_kernel 4194304 1024000000 > gpurun_out/pmc_traffic.json
-head -4 gpurun_out/r01_bench_kernel_stats.txt
-python -c 'import json; r=json.load(open("gpurun_out/r01_bench_n1.json")); print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["cpu_baseline"]["value"])'
+python tools/rocprof_summary.py /tmp/prof_bench > "$O/${TAG}_bench_kernel_stats.txt"
+python tools/rocprof_summary.py /tmp/prof_ops > "$O/${TAG}_ops_kernel_stats.txt"
+python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024000000 loss_grad=loss_grad_kernel symreg_reversed=symreg_reversed_kernel > "$O/pmc_traffic.json"
+python tools/pmc_valu.py /tmp/pmc_valu euler_jvp_kernel euler_jvp_vjp_kernel odeint_kernel symreg_linear_kernel loss_grad_kernel symreg_reversed_kernel > "$O/${TAG}_valu_pmc.json"
+python tools/pmc_mfma.py /tmp/pmc_mfma3 aug_gram_kernel > "$O/${TAG}_gram_o3_mfma_pmc.json"
+python tools/pmc_mfma.py /tmp/pmc_mfma5 aug_gram_kernel > "$O/${TAG}_gram_o5_mfma_pmc.json"
+python tools/latency_bench.py --orders 3 5 > "$O/${TAG}_latency.txt" 2>&1
+head -6 "$O/${TAG}_bench_kernel_stats.txt"
+cat "$O/pmc_traffic.json" | head -30
+cat "$O/${TAG}_valu_pmc.json" | head -60
