@@ -42,6 +42,19 @@ inline int small_grid_cap() {
     return e ? atoi(e) : 128;
 }
 
+// The vector-pipe Gram (gram_valu.hpp) holds two workgroups per CU (register-bound): one balanced round of them for a
+// single large problem, the streaming grid for batches; its partial rows are 78 doubles, so many workgroups are cheap.
+inline int gram_valu_grid(long n, long S, int d) {
+    static const long total = [] {
+        const char* e = getenv("SYMODE_GRAM_VALU_GRID");
+        const long v = e ? atol(e) : 1024;
+        return v < 2 ? 2 : v;
+    }();
+    int g = grid_x_for(n, S, d == 2 ? 2 : d == 4 ? 1 : 4);
+    if (S == 1 && g > total) g = (int)total;
+    return g;
+}
+
 // points per 16-byte chunk step (points.hpp, Chunk<D>::PPT)
 inline int ppt_for(int d) { return d == 2 ? 2 : d == 4 ? 1 : 4; }
 
@@ -171,8 +184,8 @@ int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, in
     if (!x || !dx || !gram_out) return SYMODE_E_NULLPTR;
     if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
-    const int gx = gram_grid(n, n_problems);
-    return (int)ops->aug_gram(x, dx, n_problems, n, nullptr, gram_out, (double*)workspace, gx, (hipStream_t)stream);
+    return (int)ops->aug_gram(x, dx, n_problems, n, nullptr, gram_out, (double*)workspace, gram_grid(n, n_problems),
+                              gram_valu_grid(n, n_problems, d), (hipStream_t)stream);
 }
 
 int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const int* idx, long n_problems, long m, int d,
@@ -183,8 +196,8 @@ int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const in
     if (!x || !dx || !idx || !gram_out) return SYMODE_E_NULLPTR;
     if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(idx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, m);
-    const int gx = gram_grid(m, n_problems);
-    return (int)ops->aug_gram(x, dx, n_problems, m, idx, gram_out, (double*)workspace, gx, (hipStream_t)stream);
+    return (int)ops->aug_gram(x, dx, n_problems, m, idx, gram_out, (double*)workspace, gram_grid(m, n_problems),
+                              gram_valu_grid(m, n_problems, d), (hipStream_t)stream);
 }
 
 int symode_symreg_linear(const float* z, long n, int d, int order, int flags, const float* xi, const float* mask,

@@ -40,7 +40,7 @@ struct LibOps {
                                   const float* mask, float inv_count, float* loss, float* grad, double* ws, int gx,
                                   hipStream_t st);
     hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
-                           int gx, hipStream_t st);
+                           int gx_mfma, int gx_valu, hipStream_t st);
     hipError_t (*vjp)(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
                       float* grad_xi, double* ws, int gx, hipStream_t st);
     hipError_t (*forward_jvp)(const float* x, const float* v, long n, const float* xi, const float* mask, float* out,

@@ -1,6 +1,7 @@
 // One translation unit per state dimension D instantiates every kernel for its libraries.
 #pragma once
 #include "gram.hpp"
+#include "gram_valu.hpp"
 #include "kernels.hpp"
 #include "weak.hpp"
 
@@ -20,7 +21,7 @@ constexpr LibOps make_ops() {
                   &launch_loss_grad<Lib>,
                   &launch_symreg_linear<Lib>,
                   &launch_symreg_reversed<Lib>,
-                  &launch_aug_gram<Lib>,
+                  &launch_aug_gram_any<Lib>,
                   &launch_vjp<Lib>,
                   &launch_forward_jvp<Lib>,
                   &launch_jvp_vjp<Lib>,

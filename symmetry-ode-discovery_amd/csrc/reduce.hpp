@@ -58,4 +58,41 @@ __device__ __forceinline__ void block_reduce_emit_lds(float (&acc)[NACC], float*
 
 constexpr int reduce_lds_floats(int block) { return 16 * (block + 1) + (block / 16) * 16; }
 
+// fp64 form of the same transpose reduction (per-thread fp64 partial sums: the VALU Gram kernel): KC = 8 values per
+// round, thread (part, kk) adds BLOCK/PARTS consecutive threads' partials, thread kk combines the PARTS results.
+template <int NACC, int BLOCK, typename Emit>
+__device__ __forceinline__ void block_reduce_emit_lds_f64(double (&acc)[NACC], double* lds, Emit emit) {
+    constexpr int KC = 8;
+    constexpr int PARTS = BLOCK / KC;           // 32 segments of 8 threads' partials
+    constexpr int SEG = BLOCK / PARTS;
+    constexpr int STRIDE = BLOCK + 1;
+    double* stage = lds;                         // [KC][STRIDE]
+    double* part = lds + KC * STRIDE;            // [PARTS][KC]
+    const int tid = threadIdx.x;
+    const int kk = tid % KC, pp = tid / KC;
+#pragma unroll
+    for (int k0 = 0; k0 < NACC; k0 += KC) {
+        if (k0 > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            if (k0 + j < NACC) stage[j * STRIDE + tid] = acc[k0 + j];
+        __syncthreads();
+        double s = 0.0;
+        if (k0 + kk < NACC) {
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) s += stage[kk * STRIDE + pp * SEG + i];
+        }
+        part[pp * KC + kk] = s;
+        __syncthreads();
+        if (tid < KC && k0 + tid < NACC) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) t += part[q * KC + tid];
+            emit(k0 + tid, t);
+        }
+    }
+}
+
+constexpr int reduce_lds_doubles(int block) { return 8 * (block + 1) + (block / 8) * 8; }
+
 }  // namespace symode

@@ -595,3 +595,31 @@ def test_weak_gram_fused_contraction(eng, T, K, d, order, fl):
     assert G.shape == (K, th.shape[1]) and b.shape == (K, d)
     assert torch.allclose(G.cpu(), want_G, rtol=1e-12, atol=1e-12 * want_G.abs().max().item())
     assert torch.allclose(b.cpu(), want_b, rtol=1e-12, atol=1e-12 * want_b.abs().max().item())
+
+
+@pytest.mark.parametrize("S,n,d,order,fl", [(1, 125000, 2, 3, 0), (5, 4099, 2, 2, 2), (3, 1000, 2, 2, 0), (2, 777, 1, 5, 2), (1, 3000, 3, 1, 0),
+                                            (2, 5000, 2, 5, 0)])
+def test_gram_vector_pipe_and_matrix_core_forms_agree(eng, S, n, d, order, fl):
+    """Small libraries (F = p + d <= 12) take the fp64 vector-pipe Gram (one fma per distinct entry), larger ones and
+    SYMODE_GRAM_VALU=0 the fp64 MFMA form: both are fp64 sums of exact products -- equal to 1e-12, and to the host's."""
+    torch.manual_seed(n)
+    x, dx = (torch.randn(S, n, d) * 0.7).cuda(), torch.randn(S, n, d).cuda()
+    with _env(SYMODE_GRAM_VALU=1):
+        a = eng.aug_gram(x, dx, order, fl)
+    with _env(SYMODE_GRAM_VALU=0):
+        b = eng.aug_gram(x, dx, order, fl)
+    th = eng.theta(x.reshape(-1, d), order, fl).reshape(S, n, -1)
+    A = torch.cat([th, dx], dim=2).double().cpu()
+    want = A.transpose(1, 2) @ A
+    for g in (a, b):
+        assert torch.allclose(g.cpu(), want, rtol=1e-12, atol=1e-12 * want.abs().max().item())
+    assert torch.equal(a, a.transpose(1, 2))
+    # the index-table form (seed sweeps) through both
+    idx = torch.stack([torch.randperm(n)[: n // 2] for _ in range(4)]).int().cuda()
+    with _env(SYMODE_GRAM_VALU=1):
+        ga = eng.aug_gram_gather(x[0], dx[0], idx, order, fl)
+    with _env(SYMODE_GRAM_VALU=0):
+        gb = eng.aug_gram_gather(x[0], dx[0], idx, order, fl)
+    assert torch.allclose(ga, gb, rtol=1e-12, atol=1e-12 * gb.abs().max().item())
+    Ai = A[0][idx[1].long().cpu()]
+    assert torch.allclose(ga[1].cpu(), Ai.T @ Ai, rtol=1e-12, atol=1e-12 * want.abs().max().item())
