@@ -50,9 +50,13 @@ inline int gram_valu_grid(long n, long S, int d) {
         const long v = e ? atol(e) : 1024;
         return v < 2 ? 2 : v;
     }();
-    int g = grid_x_for(n, S, d == 2 ? 2 : d == 4 ? 1 : 4);
-    if (S == 1 && g > total) g = (int)total;
-    return g;
+    // at least 32 points per thread: the epilogue transposes 78 fp64 sums per thread through LDS (ten rounds), which a
+    // thread must amortise over its own 78-fma-per-point work; beyond that, enough workgroups to fill the chip
+    long g = (n + 256L * 32 - 1) / (256L * 32);
+    const long want = (total + S - 1) / S;                 // ~`total` workgroups in all
+    if (g > want) g = want;
+    if (g < 1) g = 1;
+    return (int)g;
 }
 
 // points per 16-byte chunk step (points.hpp, Chunk<D>::PPT)

@@ -161,6 +161,11 @@ __global__ __launch_bounds__(BLOCK) void gram_valu_finalize_kernel(const double*
     }
 }
 
+inline bool gram_valu_gather_enabled() {
+    const char* e = getenv("SYMODE_GRAM_VALU_GATHER");
+    return e && e[0] == '1';
+}
+
 inline bool gram_valu_enabled() {
     const char* e = getenv("SYMODE_GRAM_VALU");       // tuning / A-B knob: 0 forces the MFMA form for every library
     return !(e && e[0] == '0');
@@ -169,8 +174,10 @@ inline bool gram_valu_enabled() {
 template <class Lib>
 hipError_t launch_aug_gram_any(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
                                int gx_mfma, int gx_valu, hipStream_t st) {
+    // index-table launches (random 8-byte rows) need more waves in flight than the register-bound vector form has:
+    // they keep the MFMA form, whose thread-per-point feature build runs at 4+ waves per SIMD
     if constexpr (GramValuShape<Lib>::OK) {
-        if (gram_valu_enabled()) {
+        if (gram_valu_enabled() && (idx == nullptr || gram_valu_gather_enabled())) {
             double* part = ws + WS_HEADER_DOUBLES;
             const bool vec = vec_ok(x, n, Lib::D, S) && vec_ok(dx, n, Lib::D, S);
             aug_gram_valu_kernel<Lib><<<dim3(gx_valu, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, vec, idx, part);

@@ -36,6 +36,9 @@ class SeedSweepSTLSQ:
             assert idx.dim() == 2 and idx.shape[0] == n_seeds
             self.idx = idx.to(torch.int32).to(x.device).contiguous()
             self.m_local = idx.shape[1]
+        # a seed's Gram is a sum over its rows: visit them in ascending order (near-sequential reads of x, dx)
+        if idx is not None:
+            self.idx = torch.sort(self.idx, dim=1).values.contiguous()
         else:
             rank = dist.get_rank(group) if group is not None else 0
             m = max(1, int(self.n_local * subsample))
@@ -43,7 +46,7 @@ class SeedSweepSTLSQ:
             for s in range(n_seeds):                      # seeded permutation per (seed, rank): reproducible subsets
                 g = torch.Generator().manual_seed(1_000_003 * (seed0 + s) + rank)
                 rows.append(torch.randperm(self.n_local, generator=g)[:m])
-            self.idx = torch.stack(rows).to(torch.int32).to(x.device)
+            self.idx = torch.sort(torch.stack(rows), dim=1).values.to(torch.int32).to(x.device)
             self.m_local = m
         self._gram = None
 
