@@ -50,6 +50,8 @@ def parse(argv=None):
     ap.add_argument("--sym_reg", choices=["r", "none"], default="r",
                     help="'r': the step includes the fused reversed symmetry regulariser (default); 'none': Theta + residual only")
     ap.add_argument("--w_sym_reg", type=float, default=0.1)
+    ap.add_argument("--two_launch_sym", action="store_true",
+                    help="A/B: residual and regulariser as two launches (x read twice) instead of the one fused closure kernel")
     ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernels (default: 1 on one GPU, 2 when the [loss|grad] buffer is all-reduced)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
@@ -176,16 +178,14 @@ def _leg(kernel, bytes_per_launch, ms_sorted, traffic=None, **extra):
 def _pmc_traffic(kernel_key, points_per_launch):
     """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate
     passes, gfx950 correction), scaled per point when it was taken on another launch size (streaming kernels)."""
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        rec = json.load(open(pmc))
-        rec = rec.get("kernels", {}).get(kernel_key) or (rec if kernel_key == "loss_grad" and "loss_grad_bytes_per_point" in rec else None)
-        if rec is None:
-            return None
-        per_point = rec.get("bytes_per_point", rec.get("loss_grad_bytes_per_point"))
-        return None if per_point is None else per_point * points_per_launch
-    except Exception:
-        return None
+    for name in ("pmc_traffic.json", "pmc_traffic_two_launch.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name))).get("kernels", {}).get(kernel_key)
+            if rec is not None and rec.get("bytes_per_point") is not None:
+                return rec["bytes_per_point"] * points_per_launch
+        except Exception:
+            pass
+    return None
 
 
 def main():
@@ -244,7 +244,7 @@ def main():
     n_chunks = a.chunks or (2 if (use_dist and a.shard == "points") else 1)
     clos = BatchedClosure(x, dx, order, Q=Q, use_kron_product=use_kron, allow_constant=True,
                           group=dist.group.WORLD if (use_dist and a.shard == "points") else None, n_chunks=n_chunks, engine=eng,
-                          reversed_sym=sym)
+                          reversed_sym=sym, fuse_sym=not a.two_launch_sym)
     g = torch.Generator(device=dev)
     g.manual_seed(7 + rank)
     beta = torch.randn(S, Q.shape[1], generator=g, device=dev) * 0.3
@@ -264,7 +264,7 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps; HIP events bracket every fused-kernel launch ----
-    with _KernelTimer(eng, "loss_grad") as t_lg, _KernelTimer(eng, "symreg_reversed") as t_sr:
+    with _KernelTimer(eng, "loss_grad") as t_lg, _KernelTimer(eng, "symreg_reversed") as t_sr, _KernelTimer(eng, "loss_grad_reversed") as t_fc:
         t0 = time.perf_counter()
         for _ in range(a.steps):
             out = step()
@@ -280,15 +280,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    launches_per_step = max(len(t_lg.events) // max(a.steps, 1), 1)
+    launches_per_step = max(max(len(t_lg.events), len(t_fc.events)) // max(a.steps, 1), 1)
     pts_per_launch = (S / launches_per_step) * n_pts
+    bpp_sym = 4 * d + 1 * (4 * d + 4 * d * d)                  # x + per group element (g(x), J_g(x)): 32 B/point at d = 2
     legs = [_leg(f"loss_grad_kernel<Library<2,{order},0>> (Theta + residual + loss + grad; last workgroup finalises)",
                  pts_per_launch * (2 * 4 * d), t_lg.ms(), _pmc_traffic("loss_grad", pts_per_launch), bytes_per_point=2 * 4 * d,
-                 in_step=True)]
-    if sym is not None:
-        bpp = 4 * d + 1 * (4 * d + 4 * d * d)               # x + per group element (g(x), J_g(x)): 32 B/point at d = 2
-        legs.append(_leg(f"symreg_reversed_kernel<Library<2,{order},0>> (S4 on precomputed g(x), J_g(x))", pts_per_launch * bpp,
-                         t_sr.ms(), _pmc_traffic("symreg_reversed", pts_per_launch), bytes_per_point=bpp, in_step=True))
+                 in_step=True),
+            _leg(f"symreg_reversed_kernel<Library<2,{order},0>,false> (S4 on precomputed g(x), J_g(x))", pts_per_launch * bpp_sym,
+                 t_sr.ms(), _pmc_traffic("symreg_reversed", pts_per_launch), bytes_per_point=bpp_sym, in_step=True),
+            # the fused closure reads x ONCE for both terms: dx + x + g(x) + J_g(x) = 40 B/point at d = 2
+            _leg(f"symreg_reversed_kernel<Library<2,{order},0>,true> (fused closure: Theta + residual + S4 + grad, x read once)",
+                 pts_per_launch * (4 * d + bpp_sym), t_fc.ms(), _pmc_traffic("closure_reversed", pts_per_launch),
+                 bytes_per_point=4 * d + bpp_sym, in_step=True)]
 
     # ---- Euler-flow pair of the infinitesimal regulariser (S2): K = 10 steps + tangent, and its reverse ----
     single = {}
@@ -369,7 +372,8 @@ def main():
     legs = [leg for leg in legs if leg is not None]
     in_step = [leg for leg in legs if leg.get("in_step")]
     dominant = max(in_step, key=lambda leg: leg["kernel_ms"] * leg["launches"])
-    parts = "Xi from beta, fused Theta+residual+loss+grad kernel" + (", fused reversed sym-reg kernel" if sym is not None else "") + ", grad->beta"
+    parts = "Xi from beta, " + ("ONE fused Theta+residual+reversed-sym-reg+loss+grad kernel" if (sym is not None and not a.two_launch_sym)
+                                else "fused Theta+residual+loss+grad kernel" + (", fused reversed sym-reg kernel" if sym is not None else "")) + ", grad->beta"
     metric = "trajectory-points/sec through Theta-build+residual+sym-reg" if sym is not None else \
         "trajectory-points/sec through Theta-build+residual (no sym-reg leg: --sym_reg none)"
     res = {

@@ -139,6 +139,16 @@ int symode_symreg_reversed_batched(const float* x, const float* gx, const float*
                                    int order, int flags, const float* xi, const float* mask, float inv_count,
                                    float* loss_out, float* grad_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The whole closure of the reversed-regulariser fit in ONE pass over the points: the residual shares Theta(x) and
+ * h(x) with the regulariser and x is read once (40 instead of 16 + 32 bytes per point at d = 2, n_g = 1):
+ *     loss2_out[s] = inv_count * ( sum r^2 , sum_g sum u^2 ),   r = h(x) - dx,  u = J_g(x) h(x) - h(g(x)),
+ *     grad_out[s]  = d( loss2[0] + w_sym * loss2[1] ) / dxi   (masked).
+ * Layouts as in symode_symreg_reversed_batched; n_g >= 1.
+ * replaces: train.py:663-664 + 675-679 + 689 with sym_reg_type 'r' (loss_sindy_x + w_sym_reg * symm_loss, backward). */
+int symode_loss_grad_reversed(const float* x, const float* dx, const float* gx, const float* jgx, int n_g, long n_problems, long n,
+                              int d, int order, int flags, const float* xi, const float* mask, float inv_count, float w_sym,
+                              float* loss2_out, float* grad_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Reverse mode of symode_forward, given g = dL/d(out) (n, d):
  *   grad_x (n, d) = J_Theta(x)^T (xi*mask)^T g   (skipped when grad_x is NULL),
  *   grad_xi (d, p) = (g^T Theta(x)) * mask.

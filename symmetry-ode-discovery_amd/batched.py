@@ -20,10 +20,11 @@ from .engine import get_engine, library_flags
 
 class BatchedClosure:
     def __init__(self, x, dx, poly_order, include_sine=False, include_exp=False, Q=None, use_kron_product=True,
-                 allow_constant=True, group=None, world_size=None, n_chunks=1, engine=None, reversed_sym=None):
+                 allow_constant=True, group=None, world_size=None, n_chunks=1, engine=None, reversed_sym=None, fuse_sym=True):
         """``reversed_sym = (gx (S, n_g, N_local, d), jgx (S, n_g, N_local, d, d), weight)`` adds  weight * the reversed
         symmetry regulariser (model_utils.py:126-170 on precomputed (g(x), J_g(x))) to every problem's loss and gradient:
-        one more fused launch per chunk, summed into the same packed buffer before the collective."""
+        by default residual and regulariser run as ONE launch per chunk (symode_loss_grad_reversed: Theta(x) shared, x read
+        once); ``fuse_sym=False`` keeps them as two launches summed into the same packed buffer before the collective."""
         assert x.dim() == 3 and x.shape == dx.shape, "x, dx must be (S, N_local, d)"
         self.engine = engine or get_engine()
         self.x, self.dx = x.contiguous(), dx.contiguous()
@@ -50,6 +51,7 @@ class BatchedClosure:
             assert gx.dim() == 4 and gx.shape[0] == self.S and gx.shape[2:] == x.shape[1:] and jgx.shape == gx.shape + (self.d,)
             self.sym = (gx.contiguous(), jgx.contiguous(), float(weight))
             self.sym_buffers = [torch.empty_like(b) for b in self.buffers]
+        self.fuse_sym = fuse_sym
 
     # -- coefficient plumbing (batched get_Xi, sindy.py:169-176) ----------------------------
     def xi_from(self, beta, const=None):
@@ -74,10 +76,24 @@ class BatchedClosure:
     def loss_grad_xi(self, Xi, mask=None):
         """loss (S,), dloss/dXi (S, d, p) summed over all ranks' shards."""
         works = []
+        fused = self.sym is not None and self.fuse_sym and hasattr(self.engine, 'loss_grad_reversed')
         for ci, ((a, b), buf) in enumerate(zip(self.chunks, self.buffers)):
             n = b - a
             loss = buf[:n]
             grad = buf[n:].view(n, self.d, self.p)
+            if fused:
+                # ONE launch per chunk: residual and regulariser share Theta(x), x is read once; the kernel leaves
+                # (mse, regulariser) per problem and the gradient of mse + weight * regulariser
+                gx, jgx, weight = self.sym
+                sb = self.sym_buffers[ci]
+                l2 = sb[:2 * n].view(n, 2)
+                self.engine.loss_grad_reversed(self.x[a:b], self.dx[a:b], gx[a:b], jgx[a:b], Xi[a:b],
+                                               None if mask is None else mask[a:b], self.order, self.flags, w_sym=weight,
+                                               inv_count=self.inv_count, out=(l2, grad))
+                torch.add(l2[:, 0], l2[:, 1], alpha=weight, out=loss)
+                if self.distributed:
+                    works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                continue
             l, g = self.engine.loss_grad(self.x[a:b], self.dx[a:b], Xi[a:b], None if mask is None else mask[a:b],
                                          self.order, self.flags, inv_count=self.inv_count, out=(loss, grad))
             if l.data_ptr() != loss.data_ptr():          # an engine that does not write in place

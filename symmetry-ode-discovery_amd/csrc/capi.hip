@@ -67,7 +67,7 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
     const int F = ops->p + ops->d;
     const int T = (F + 15) / 16;
     const size_t gram_partial = (size_t)(T * (T + 1) / 2) * 256;
-    const size_t nacc = 1 + (size_t)ops->d * ops->p;
+    const size_t nacc = 2 + (size_t)ops->d * ops->p;          // widest row: the fused closure keeps two scalar sums
     const size_t g_red = (size_t)grid_x_for(n, S, 1);   // widest grid any reduction uses
     const size_t a = (size_t)S * g_red * nacc;
     const size_t b = (size_t)S * g_red * gram_partial;
@@ -232,7 +232,26 @@ int symode_symreg_reversed_batched(const float* x, const float* gx_, const float
         const int cap = small_grid_cap();
         if (cap > 0 && gx > cap) gx = cap;
     }
-    return (int)ops->symreg_reversed(x, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, loss_out, grad_out,
+    return (int)ops->symreg_reversed(x, nullptr, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, 1.0f, loss_out, grad_out,
+                                     (double*)workspace, gx, (hipStream_t)stream);
+}
+
+int symode_loss_grad_reversed(const float* x, const float* dx, const float* gx_, const float* jgx, int n_g, long n_problems, long n,
+                              int d, int order, int flags, const float* xi, const float* mask, float inv_count, float w_sym,
+                              float* loss2_out, float* grad_out, void* workspace, size_t workspace_bytes, void* stream) {
+    SYMODE_GET_OPS();
+    if (n < 1 || n_g < 1 || n_problems < 1 || n_problems > 65535) return SYMODE_E_BADSIZE;
+    if (!x || !dx || !xi || !loss2_out || !grad_out || !gx_ || !jgx) return SYMODE_E_NULLPTR;
+    if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(gx_, 4) || misaligned(jgx, 4) || misaligned(xi, 4) || misaligned(mask, 4) ||
+        misaligned(loss2_out, 4) || misaligned(grad_out, 4))
+        return SYMODE_E_ALIGN;
+    SYMODE_CHECK_WS(n_problems, n);
+    int gx = grid_x_for(n, n_problems, ppt_for(d));
+    if (n_problems == 1 && gx <= 512) {
+        const int cap = small_grid_cap();
+        if (cap > 0 && gx > cap) gx = cap;
+    }
+    return (int)ops->symreg_reversed(x, dx, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, w_sym, loss2_out, grad_out,
                                      (double*)workspace, gx, (hipStream_t)stream);
 }
 

@@ -36,9 +36,10 @@ struct LibOps {
                             float inv_count, float* loss, float* grad, double* ws, int gx, hipStream_t st);
     hipError_t (*symreg_linear)(const float* z, long n, const float* xi, const float* mask, const float* L, int n_gen,
                                 float* loss, float* grad, double* ws, int gx, hipStream_t st);
-    hipError_t (*symreg_reversed)(const float* x, const float* gx_, const float* jgx, int n_g, long S, long n, const float* xi,
-                                  const float* mask, float inv_count, float* loss, float* grad, double* ws, int gx,
-                                  hipStream_t st);
+    // dx == nullptr: the regulariser alone (loss (S)); else the fused closure MSE + w_sym * regulariser (loss (S, 2))
+    hipError_t (*symreg_reversed)(const float* x, const float* dx, const float* gx_, const float* jgx, int n_g, long S, long n,
+                                  const float* xi, const float* mask, float inv_count, float w_sym, float* loss, float* grad,
+                                  double* ws, int gx, hipStream_t st);
     hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
                            int gx_mfma, int gx_valu, hipStream_t st);
     hipError_t (*vjp)(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
@@ -313,8 +314,9 @@ struct Finish {
     const float* mask;               // (S, NACC-1) or null
     float loss_scale, grad_scale;
     float* loss;                     // (S) or null
-    float* grad;                     // (S, NACC-1)
+    float* grad;                     // (S, NACC - n_loss)
     int fused;                       // 1: last-block finalisation inside this launch
+    int n_loss;                      // leading scalar sums per problem (1; 2 for the fused MSE + regulariser closure)
 };
 
 __device__ __forceinline__ unsigned* ws_tickets(unsigned long long* header) {
@@ -325,7 +327,7 @@ __device__ __forceinline__ unsigned* ws_tickets(unsigned long long* header) {
 // part, part + 4, ... of value k = k0 + lane; the 4 parts are combined in fixed order through LDS.
 // SC1: rows come from other workgroups of the SAME launch (agent-scope loads), else plain loads.
 template <bool SC1>
-__device__ __forceinline__ void combine_rows(const double* __restrict__ src, int G, int nacc, long s,
+__device__ __forceinline__ void combine_rows(const double* __restrict__ src, int G, int nacc, int n_loss, long s,
                                              const float* __restrict__ mask, float loss_scale, float grad_scale,
                                              float* __restrict__ loss, float* __restrict__ grad, double* comb) {
     auto ld = [&](long i) -> double {
@@ -355,10 +357,10 @@ __device__ __forceinline__ void combine_rows(const double* __restrict__ src, int
         __syncthreads();
         if (part == 0 && k < nacc) {
             v = comb[lane] + comb[WAVE + lane] + comb[2 * WAVE + lane] + comb[3 * WAVE + lane];
-            if (k == 0) {
-                if (loss != nullptr) loss[s] = (float)(v * (double)loss_scale);
+            if (k < n_loss) {
+                if (loss != nullptr) loss[s * n_loss + k] = (float)(v * (double)loss_scale);
             } else {
-                const long i = s * (nacc - 1) + (k - 1);
+                const long i = s * (nacc - n_loss) + (k - n_loss);
                 const float m = mask ? mask[i] : 1.0f;
                 grad[i] = (float)(v * (double)grad_scale) * m;
             }
@@ -379,8 +381,8 @@ __device__ __forceinline__ void emit_partials(float (&acc)[NACC], double* __rest
     }
     if (fin.header[0] != WS_MAGIC) {                     // workspace never initialised: fail loudly, touch no ticket
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (fin.loss != nullptr) fin.loss[s] = __builtin_nanf("");
-            fin.grad[s * (NACC - 1)] = __builtin_nanf("");
+            if (fin.loss != nullptr) fin.loss[s * fin.n_loss] = __builtin_nanf("");
+            fin.grad[s * (NACC - fin.n_loss)] = __builtin_nanf("");
         }
         return;
     }
@@ -398,21 +400,21 @@ __device__ __forceinline__ void emit_partials(float (&acc)[NACC], double* __rest
     if (last_flag == 0u) return;
     double* comb = reinterpret_cast<double*>(lds);       // BLOCK doubles fit in the staging area
     static_assert(sizeof(float) * reduce_lds_floats(BLOCK) >= sizeof(double) * BLOCK, "LDS too small for the combine");
-    combine_rows<true>(part + s * (long)G * NACC, G, NACC, s, fin.mask, fin.loss_scale, fin.grad_scale, fin.loss, fin.grad,
-                       comb);
+    combine_rows<true>(part + s * (long)G * NACC, G, NACC, fin.n_loss, s, fin.mask, fin.loss_scale, fin.grad_scale, fin.loss,
+                       fin.grad, comb);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 // out[0] = loss_scale * sum_0 ; grad[k-1] = grad_scale * sum_k * mask[k-1]
 // (a template only so that the header-defined kernel has vague linkage across the per-D TUs)
 template <int TAG = 0>
-__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restrict__ ws, int G, int nacc,
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double* __restrict__ ws, int G, int nacc, int n_loss,
                                                          const float* __restrict__ mask, float loss_scale,
                                                          float grad_scale, float* __restrict__ loss,
                                                          float* __restrict__ grad) {
     __shared__ double comb[BLOCK];
     const long s = blockIdx.x;
-    combine_rows<false>(ws + s * (long)G * nacc, G, nacc, s, mask, loss_scale, grad_scale, loss, grad, comb);
+    combine_rows<false>(ws + s * (long)G * nacc, G, nacc, n_loss, s, mask, loss_scale, grad_scale, loss, grad, comb);
 }
 
 template <int TAG = 0>
@@ -949,16 +951,21 @@ struct JChunk {
     static_assert(Chunk<D>::PPT * D * D == NV * 4, "Jacobian chunk must be whole 16-byte vectors");
 };
 
-template <class Lib>
-__global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __restrict__ x,
+// MSE = true: the whole closure of the reversed-regulariser runs in ONE pass -- the residual r = h(x) - dx shares
+// Theta(x) and h(x) with the regulariser, x is read once (40 instead of 16 + 32 bytes per point at D = 2, n_g = 1):
+//   sums[0] = sum r^2, sums[1] = sum_g sum u^2,  grad = d( sums[0] + w_sym sums[1] ) / dXi  (both under the same 1/(N D)).
+template <class Lib, bool MSE>
+__global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                                 const float* __restrict__ gx,
                                                                 const float* __restrict__ jgx, int n_g, long N, bool vec,
                                                                 const float* __restrict__ xi,
-                                                                const float* __restrict__ mask,
+                                                                const float* __restrict__ mask, float w_sym,
                                                                 double* __restrict__ ws, Finish fin) {
-    constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NVJ = JChunk<D>::NV;
+    constexpr int D = Lib::D, P = Lib::P, NL = MSE ? 2 : 1, NACC = NL + D * P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV,
+                  NVJ = JChunk<D>::NV, SYM0 = NL - 1;
     const long s = blockIdx.y;
     const float* xs = x + s * N * D;
+    const float* ys = MSE ? dx + s * N * D : nullptr;
     const float* gs = gx + s * (long)n_g * N * D;
     const float* js = jgx + s * (long)n_g * N * D * D;
     float w[D * P];
@@ -966,9 +973,11 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    const float ws_ = MSE ? w_sym : 1.0f;
 
-    // one point against one group element: th, h belong to x (shared by all group elements of the point)
-    auto one = [&](const float (&th)[P], const float (&h)[D], const float (&gp)[D], const float (&J)[D * D]) {
+    // one point against one group element: th, h belong to x (shared by all group elements of the point);
+    // `extra` (MSE form, first group element only) is the residual r, whose gradient rides on the same Theta(x) products
+    auto one = [&](const float (&th)[P], const float (&h)[D], const float (&gp)[D], const float (&J)[D * D], const float (&extra)[D]) {
         float thg[P], hg[D], u[D], jtu[D];
         Lib::eval(gp, thg);
         apply_xi<Lib>(w, thg, hg);
@@ -978,19 +987,29 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
 #pragma unroll
             for (int b = 0; b < D; ++b) t = fmaf(J[a * D + b], h[b], t);
             u[a] = t;
-            acc[0] = fmaf(t, t, acc[0]);
+            acc[SYM0] = fmaf(t, t, acc[SYM0]);
         }
 #pragma unroll
         for (int b = 0; b < D; ++b) {
             float t = 0.0f;
 #pragma unroll
             for (int a = 0; a < D; ++a) t = fmaf(J[a * D + b], u[a], t);
-            jtu[b] = t;
+            jtu[b] = MSE ? fmaf(ws_, t, extra[b]) : t;
         }
 #pragma unroll
-        for (int j = 0; j < D; ++j)
+        for (int j = 0; j < D; ++j) {
+            const float uj = MSE ? ws_ * u[j] : u[j];
 #pragma unroll
-            for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(jtu[j], th[k], fmaf(-u[j], thg[k], acc[1 + j * P + k]));
+            for (int k = 0; k < P; ++k) acc[NL + j * P + k] = fmaf(jtu[j], th[k], fmaf(-uj, thg[k], acc[NL + j * P + k]));
+        }
+    };
+    // residual of one point (MSE form): r = h - dx, sums[0] += r^2; returned for the first group element's `extra`
+    auto resid = [&](const float (&h)[D], const float (&yp)[D], float (&r)[D]) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            r[j] = h[j] - yp[j];
+            acc[0] = fmaf(r[j], r[j], acc[0]);
+        }
     };
     auto load_j = [&](const float* base, long c, float4 (&v)[NVJ]) {
         typedef float f4v __attribute__((ext_vector_type(4)));
@@ -1002,7 +1021,8 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
         }
     };
     // the chunk's points against group element g, operands already in registers
-    auto chunk_g = [&](const float (&th)[PPT][P], const float (&h)[PPT][D], const float4 (&vg)[NV], const float4 (&vj)[NVJ]) {
+    auto chunk_g = [&](const float (&th)[PPT][P], const float (&h)[PPT][D], const float4 (&vg)[NV], const float4 (&vj)[NVJ],
+                       const float (&extra)[PPT][D]) {
         float gp[PPT][D], jf[NVJ * 4];
         unpack_chunk<D>(vg, gp);
 #pragma unroll
@@ -1017,21 +1037,31 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
             float J[D * D];
 #pragma unroll
             for (int e = 0; e < D * D; ++e) J[e] = jf[i * D * D + e];
-            one(th[i], h[i], gp[i], J);
+            one(th[i], h[i], gp[i], J, extra[i]);
         }
     };
     auto point = [&](long n) {
-        float xp[D], th[P], h[D];
+        float xp[D], th[P], h[D], r[D], zero[D];
         load_point<D>(xs, n, xp);
         Lib::eval(xp, th);
         apply_xi<Lib>(w, th, h);
+#pragma unroll
+        for (int j = 0; j < D; ++j) r[j] = zero[j] = 0.0f;
+        if constexpr (MSE) {
+            float yp[D];
+            load_point<D>(ys, n, yp);
+            resid(h, yp, r);
+        }
         for (int g = 0; g < n_g; ++g) {
             float gp[D], J[D * D];
             load_point<D>(gs + (long)g * N * D, n, gp);
             const float* Jp = js + ((long)g * N + n) * D * D;
 #pragma unroll
             for (int e = 0; e < D * D; ++e) J[e] = Jp[e];
-            one(th, h, gp, J);
+            if (g == 0)
+                one(th, h, gp, J, r);
+            else
+                one(th, h, gp, J, zero);
         }
     };
     auto eval_x = [&](const float4 (&vx)[NV], float (&th)[PPT][P], float (&h)[PPT][D]) {
@@ -1046,38 +1076,51 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
 
     const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
     // one chunk: its points' Theta(x), h(x) are formed once and live only while this chunk's group elements are visited
-    auto chunk_all = [&](long c, const float4 (&vx)[NV], const float4 (&vg)[NV], const float4 (&vj)[NVJ]) {
-        float th[PPT][P], h[PPT][D];
+    auto chunk_all = [&](long c, const float4 (&vx)[NV], const float4 (&vy)[NV], const float4 (&vg)[NV], const float4 (&vj)[NVJ]) {
+        float th[PPT][P], h[PPT][D], r[PPT][D], zero[PPT][D];
         eval_x(vx, th, h);
-        chunk_g(th, h, vg, vj);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) r[i][j] = zero[i][j] = 0.0f;
+        if constexpr (MSE) {
+            float yp[PPT][D];
+            unpack_chunk<D>(vy, yp);
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) resid(h[i], yp[i], r[i]);
+        }
+        chunk_g(th, h, vg, vj, r);
         for (int g = 1; g < n_g; ++g) {
             float4 ng[NV], nj[NVJ];
             load_chunk_raw<D, true>(gs + (long)g * N * D, c, ng);
             load_j(js + (long)g * N * D * D, c, nj);
-            chunk_g(th, h, ng, nj);
+            chunk_g(th, h, ng, nj, zero);
         }
     };
     if (vec && n_g > 0) {
         const long nchunks = N / PPT;
         long c = tid;
         for (; c + nthreads < nchunks; c += 2 * nthreads) {
-            // both chunks' x, g(x), J_g of the first group element in flight before any arithmetic
-            float4 ax[NV], bx[NV], ag[NV], bg[NV], aj[NVJ], bj[NVJ];
+            // both chunks' x, (dx,) g(x), J_g of the first group element in flight before any arithmetic
+            float4 ax[NV], bx[NV], ay[NV], by[NV], ag[NV], bg[NV], aj[NVJ], bj[NVJ];
             load_chunk_raw<D, true>(xs, c, ax);
+            if constexpr (MSE) load_chunk_raw<D, true>(ys, c, ay);
             load_chunk_raw<D, true>(gs, c, ag);
             load_j(js, c, aj);
             load_chunk_raw<D, true>(xs, c + nthreads, bx);
+            if constexpr (MSE) load_chunk_raw<D, true>(ys, c + nthreads, by);
             load_chunk_raw<D, true>(gs, c + nthreads, bg);
             load_j(js, c + nthreads, bj);
-            chunk_all(c, ax, ag, aj);
-            chunk_all(c + nthreads, bx, bg, bj);
+            chunk_all(c, ax, ay, ag, aj);
+            chunk_all(c + nthreads, bx, by, bg, bj);
         }
         if (c < nchunks) {
-            float4 ax[NV], ag[NV], aj[NVJ];
+            float4 ax[NV], ay[NV], ag[NV], aj[NVJ];
             load_chunk_raw<D, true>(xs, c, ax);
+            if constexpr (MSE) load_chunk_raw<D, true>(ys, c, ay);
             load_chunk_raw<D, true>(gs, c, ag);
             load_j(js, c, aj);
-            chunk_all(c, ax, ag, aj);
+            chunk_all(c, ax, ay, ag, aj);
         }
         const long n = nchunks * PPT + tid;
         if (n < N) point(n);
@@ -1628,14 +1671,14 @@ __global__ __launch_bounds__(Lib::D* WAVE) void loss_grad_rows_kernel(const floa
 // `ws` of every launcher below is the caller's workspace base: [header | partials].
 inline Finish make_finish(double* ws, const float* mask, float loss_scale, float grad_scale, float* loss, float* grad) {
     return Finish{reinterpret_cast<unsigned long long*>(ws), mask, loss_scale, grad_scale, loss, grad,
-                  fused_finalize_enabled() ? 1 : 0};
+                  fused_finalize_enabled() ? 1 : 0, 1};
 }
 
 // second launch of the two-launch path
 inline hipError_t launch_finalize(const Finish& fin, double* part, long S, int gx, int nacc, hipStream_t st) {
     if (fin.fused) return hipSuccess;
-    finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(part, gx, nacc, fin.mask, fin.loss_scale, fin.grad_scale,
-                                                               fin.loss, fin.grad);
+    finalize_kernel<0><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(part, gx, nacc, fin.n_loss, fin.mask, fin.loss_scale,
+                                                               fin.grad_scale, fin.loss, fin.grad);
     return hipGetLastError();
 }
 
@@ -1710,19 +1753,27 @@ hipError_t launch_symreg_linear(const float* z, long n, const float* xi, const f
 }
 
 template <class Lib>
-hipError_t launch_symreg_reversed(const float* x, const float* gxp, const float* jgx, int n_g, long S, long n, const float* xi,
-                                  const float* mask, float inv_count, float* loss, float* grad, double* ws, int gx,
-                                  hipStream_t st) {
-    constexpr int NACC = 1 + Lib::D * Lib::P, D = Lib::D;
+hipError_t launch_symreg_reversed(const float* x, const float* dx, const float* gxp, const float* jgx, int n_g, long S, long n,
+                                  const float* xi, const float* mask, float inv_count, float w_sym, float* loss, float* grad,
+                                  double* ws, int gx, hipStream_t st) {
+    constexpr int D = Lib::D;
+    const bool mse = dx != nullptr;
+    const int nacc = (mse ? 2 : 1) + D * Lib::P;
     double* part = ws + WS_HEADER_DOUBLES;
-    const Finish fin = make_finish(ws, mask, inv_count, 2.0f * inv_count, loss, grad);
+    Finish fin = make_finish(ws, mask, inv_count, 2.0f * inv_count, loss, grad);
+    fin.n_loss = mse ? 2 : 1;
     // 16-byte vectors need every slab (problem, group element) to start on a 16-byte boundary
     const bool multi = S > 1 || n_g > 1;
     const bool vec = ((uintptr_t)x % 16 == 0) && ((uintptr_t)gxp % 16 == 0) && ((uintptr_t)jgx % 16 == 0) &&
-                     (!multi || ((n * D) % 4 == 0 && (n * D * D) % 4 == 0));
-    symreg_reversed_kernel<Lib><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, gxp, jgx, n_g, n, vec, xi, mask, part, fin);
+                     (!mse || (uintptr_t)dx % 16 == 0) && (!multi || ((n * D) % 4 == 0 && (n * D * D) % 4 == 0));
+    if (mse)
+        symreg_reversed_kernel<Lib, true><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, gxp, jgx, n_g, n, vec, xi, mask, w_sym,
+                                                                                       part, fin);
+    else
+        symreg_reversed_kernel<Lib, false><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, nullptr, gxp, jgx, n_g, n, vec, xi, mask,
+                                                                                        1.0f, part, fin);
     SYMODE_LAUNCH_CHECK();
-    return launch_finalize(fin, part, S, gx, NACC, st);
+    return launch_finalize(fin, part, S, gx, nacc, st);
 }
 
 template <class Lib>

@@ -46,6 +46,8 @@ _SIGNATURES = {
                                                c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_weak_gram": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
+    "symode_loss_grad_reversed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_long, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_vjp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
     "symode_forward_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -326,6 +328,43 @@ class HipEngine:
             return loss.reshape(-1)[0], grad.reshape(d, p)
         return loss, grad
 
+
+    def loss_grad_reversed(self, x, dx, gx, jgx, xi, mask, order, flags=0, w_sym=1.0, inv_count=None, out=None, ws=None):
+        """The closure MSE + w_sym * reversed regulariser in ONE pass (x read once, Theta(x) shared by both terms).
+        Shapes as loss_grad / symreg_reversed.  Returns (loss2, grad): loss2 (S, 2) [or (2,)] = (mse, regulariser), grad =
+        d(mse + w_sym * regulariser)/dXi (S, d, p) [or (d, p)]."""
+        x, dx, gx, jgx = self._dev(x, "x"), self._dev(dx, "dx"), self._dev(gx, "gx"), self._dev(jgx, "jgx")
+        if x.shape != dx.shape:
+            raise SymodeError(f"x {tuple(x.shape)} and dx {tuple(dx.shape)} differ")
+        batched = x.dim() == 3
+        S = x.shape[0] if batched else 1
+        n, d = x.shape[-2], x.shape[-1]
+        n_g = gx.shape[1] if batched else gx.shape[0]
+        want_g = (S, n_g, n, d) if batched else (n_g, n, d)
+        if n_g < 1 or tuple(gx.shape) != want_g or tuple(jgx.shape) != want_g + (d,):
+            raise SymodeError(f"gx {tuple(gx.shape)} / jgx {tuple(jgx.shape)} do not match x {tuple(x.shape)}")
+        xi = self._dev_or_pinned(xi, "xi")
+        mask = None if mask is None else self._dev(mask, "mask")
+        p = self._check_coef(xi, mask, d, order, flags, S)
+        if out is None:
+            loss2 = torch.empty(S, 2, dtype=torch.float32, device=x.device)
+            grad = torch.empty(S, d, p, dtype=torch.float32, device=x.device)
+        else:
+            loss2, grad = (self._dev_or_pinned(o, "out") for o in out)
+            if loss2.numel() != 2 * S or grad.numel() != S * d * p:
+                raise SymodeError(f"out buffers hold {loss2.numel()} / {grad.numel()} elements, expected {2 * S} / {S * d * p}")
+        if ws is None:
+            ws = self.workspace(x.device, d, order, flags, S, n)
+        elif ws.numel() * 8 < self.lib.symode_workspace_bytes(d, order, flags, S, n):
+            raise SymodeError("private workspace too small for this call")
+        inv = 1.0 / (n * d) if inv_count is None else float(inv_count)
+        self._check(self.lib.symode_loss_grad_reversed(self._ptr(x), self._ptr(dx), self._ptr(gx), self._ptr(jgx), n_g, S, n, d, order,
+                                                       flags, self._ptr(xi), self._ptr(mask), inv, float(w_sym), self._ptr(loss2),
+                                                       self._ptr(grad), self._ptr(ws), ws.numel() * 8, self._stream(x)),
+                    "symode_loss_grad_reversed")
+        if not batched:
+            return loss2.reshape(2), grad.reshape(d, p)
+        return loss2.reshape(S, 2), grad.reshape(S, d, p)
 
     def weak_gram(self, x, V, V_drv, order, flags=0):
         """Weak-SINDy contraction: x (T, d) one trajectory, V / V_drv (K, T) -> (G = V Theta(x) (K, p), b = -V_drv x (K, d)), fp64."""

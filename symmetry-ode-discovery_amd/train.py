@@ -339,6 +339,18 @@ class _HostShadow:
             reg.engine.symreg_reversed(self.x, gx, jgx, self.h_xi, reg.mask, reg.poly_order, reg.flags,
                                        out=(self.h_out[n:n + 1], self.h_out[n + 1:].view(d, p)), **self._kw())
 
+    def evaluate_fused(self, w_ratio):
+        """Reversed-regulariser closure as ONE launch (symode_loss_grad_reversed): returns (Xi, mse, sym, d(mse + w_ratio sym)/dXi)
+        through the pinned buffers; ``w_ratio`` = w_sym_reg / w_sindy_x."""
+        reg, (d, p), n = self.reg, self.mask.shape, self.n_out
+        Xi = self.get_Xi()
+        self.h_xi.copy_(Xi.detach())
+        gx, jgx = self.reversed_sym
+        reg.engine.loss_grad_reversed(self.x, self.dx, gx, jgx, self.h_xi, reg.mask, reg.poly_order, reg.flags, w_sym=w_ratio,
+                                      out=(self.h_out[:2], self.h_out[2:2 + d * p].view(d, p)), **self._kw())
+        torch.cuda.current_stream(self.x.device).synchronize()
+        return Xi, self.h_out[0].clone(), self.h_out[1].clone(), self.h_out[2:2 + d * p].view(d, p).clone()
+
     def _zero_copy_works(self):
         try:
             self.h_xi.copy_(self.get_Xi().detach())
@@ -676,15 +688,22 @@ def train_SIGED_lbfgs(
                 raise ValueError(f'Unknown regularization type: {sindy_reg_type}')
             return loss, g.astype(np.float32)
 
+        one_launch = (rev is not None and shadow.zero_copy and w_sindy_x > 0 and hasattr(regressor.engine, 'loss_grad_reversed'))
+
         def closure(optimizer):                                                        # same terms as train.py:645-690
             optimizer.zero_grad()
-            Xi, vals, grads = shadow.evaluate()
             lin = lambda v, g: v + (g * (Xi - Xi.detach())).sum()                      # value + exact first-order term  # noqa: E731
-            losses['loss_sindy_x'] = vals[0]
-            loss = w_sindy_x * lin(vals[0], grads[0])
-            if rev is not None:
-                losses['loss_sym_reg'] = vals[1]
-                loss = loss + w_sym_reg * lin(vals[1], grads[1])
+            if one_launch:                                                             # MSE + regulariser: one pass over the points
+                Xi, mse, sym, g_tot = shadow.evaluate_fused(w_sym_reg / w_sindy_x)
+                losses['loss_sindy_x'], losses['loss_sym_reg'] = mse, sym
+                loss = lin(w_sindy_x * mse + w_sym_reg * sym, w_sindy_x * g_tot)
+            else:
+                Xi, vals, grads = shadow.evaluate()
+                losses['loss_sindy_x'] = vals[0]
+                loss = w_sindy_x * lin(vals[0], grads[0])
+                if rev is not None:
+                    losses['loss_sym_reg'] = vals[1]
+                    loss = loss + w_sym_reg * lin(vals[1], grads[1])
             if sindy_reg_type == 'l1':
                 loss_sindy_reg = sum(torch.norm(p, 1) for p in shadow.parameters())
                 losses['loss_sindy_reg'] = loss_sindy_reg.detach()

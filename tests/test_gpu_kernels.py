@@ -623,3 +623,33 @@ def test_gram_vector_pipe_and_matrix_core_forms_agree(eng, S, n, d, order, fl):
     assert torch.allclose(ga, gb, rtol=1e-12, atol=1e-12 * gb.abs().max().item())
     Ai = A[0][idx[1].long().cpu()]
     assert torch.allclose(ga[1].cpu(), Ai.T @ Ai, rtol=1e-12, atol=1e-12 * want.abs().max().item())
+
+
+@pytest.mark.parametrize("S,n,n_g,d,order,fl", [(1, 20000, 1, 2, 2, 2), (3, 4096, 2, 2, 3, 0), (2, 125000, 1, 2, 5, 0), (1, 777, 3, 3, 2, 1), (2, 301, 1, 1, 4, 0)])
+def test_fused_closure_mse_plus_reversed_regulariser(eng, S, n, n_g, d, order, fl):
+    """symode_loss_grad_reversed: residual and regulariser in one pass (x read once) == the two separate launches, and
+    the oracle's MSE + w * symreg_reversed_precomputed with its autograd gradient."""
+    torch.manual_seed(S + n)
+    p = eng.lib_size(d, order, fl)
+    x = torch.randn(S, n, d) * 0.5
+    dx = torch.randn(S, n, d)
+    gx = x[:, None] + 0.05 * torch.randn(S, n_g, n, d)
+    jgx = torch.eye(d) + 0.05 * torch.randn(S, n_g, n, d, d)
+    xi = torch.randn(S, d, p) * 0.3
+    mask = (torch.rand(S, d, p) > 0.25).float()
+    w = 0.37
+    c = [a.cuda() for a in (x, dx, gx, jgx, xi, mask)]
+    loss2, grad = eng.loss_grad_reversed(c[0], c[1], c[2], c[3], c[4], c[5], order, fl, w_sym=w)
+    l_m, g_m = eng.loss_grad(c[0], c[1], c[4], c[5], order, fl)
+    l_s, g_s = eng.symreg_reversed(c[0], c[2], c[3], c[4], c[5], order, fl)
+    assert loss2.shape == (S, 2) and grad.shape == (S, d, p)
+    assert torch.allclose(loss2[:, 0], l_m, rtol=2e-6) and torch.allclose(loss2[:, 1], l_s, rtol=2e-6)
+    assert_close_scaled(grad.cpu(), (g_m + w * g_s).cpu(), 3e-6, "fused vs two launches")
+    for s in range(S):
+        reg = O.OracleRegressor(d, order, bool(fl & 1), bool(fl & 2), Xi0=xi[s])
+        reg.mask = mask[s]
+        mse = torch.nn.functional.mse_loss(reg(x[s]), dx[s])
+        sym = O.symreg_reversed_precomputed(x[s], list(gx[s]), list(jgx[s]), reg)
+        (mse + w * sym).backward()
+        assert np.isclose(loss2[s, 0].item(), mse.item(), rtol=2e-5) and np.isclose(loss2[s, 1].item(), sym.item(), rtol=2e-5)
+        assert_close_scaled(grad[s].cpu(), reg.Xi.grad * mask[s], 3e-5, f"fused closure grad, problem {s}")

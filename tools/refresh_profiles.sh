@@ -8,12 +8,15 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O="$R/gpurun_out"
 mkdir -p "$O"
 cd "$R" && python bench.py > "$O/${TAG}_bench_n1.json" 2> "$O/${TAG}_bench_n1.err" && echo "bench done"
+python bench.py --two_launch_sym --no_cpu_baseline --steps 50 > "$O/${TAG}_bench_n1_two_launch.json" 2>/dev/null && echo "two-launch bench done"
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations of the bench step (same command, profiling mode: only the K batched steps)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 "$R/bench.py" --steps 20 --warmup 3 --profile > /dev/null 2>&1 && echo "trace done"
 # HBM traffic: separate PMC passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile > /dev/null 2>&1 && echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile > /dev/null 2>&1 && echo "write done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch2 -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile --two_launch_sym > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write2 -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile --two_launch_sym > /dev/null 2>&1 && echo "two-launch traffic done"
 # every streaming entry point at 2^26 points under the kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ops -- python3 "$R/tools/kbench.py" --table --S 1 --N 67108864 --libs 3:0,2:2 --reps 3 > "$O/${TAG}_ops_roofline.md" 2>/dev/null && echo "ops done"
 # VALU counters of the arithmetic-bound kernels, MFMA counters of the Gram
@@ -23,7 +26,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MF
 cd "$R"
 python tools/rocprof_summary.py /tmp/prof_bench > "$O/${TAG}_bench_kernel_stats.txt"
 python tools/rocprof_summary.py /tmp/prof_ops > "$O/${TAG}_ops_kernel_stats.txt"
-python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024000000 loss_grad=loss_grad_kernel symreg_reversed=symreg_reversed_kernel > "$O/pmc_traffic.json"
+python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024000000 "closure_reversed=symreg_reversed_kernel<symode::Library<2, 5, 0>, true>" > "$O/pmc_traffic.json"
+python tools/pmc_traffic.py /tmp/pmc_fetch2 /tmp/pmc_write2 1024000000 loss_grad=loss_grad_kernel "symreg_reversed=symreg_reversed_kernel<symode::Library<2, 5, 0>, false>" > "$O/pmc_traffic_two_launch.json"
 python tools/pmc_valu.py /tmp/pmc_valu euler_jvp_kernel euler_jvp_vjp_kernel odeint_kernel symreg_linear_kernel loss_grad_kernel symreg_reversed_kernel > "$O/${TAG}_valu_pmc.json"
 python tools/pmc_mfma.py /tmp/pmc_mfma3 aug_gram_kernel > "$O/${TAG}_gram_o3_mfma_pmc.json"
 python tools/pmc_mfma.py /tmp/pmc_mfma5 aug_gram_kernel > "$O/${TAG}_gram_o5_mfma_pmc.json"
