@@ -543,7 +543,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["ranks_observed"] == 2 and rec["warmup"] == 1 and rec["steps"] == 3
-    assert rec["metric"].endswith("sym-reg") and len(rec["roofline_legs"]) == 2 and rec["value"] > 0
+    assert rec["metric"].endswith("sym-reg") and len(rec["roofline_legs"]) == 1 and rec["value"] > 0      # ONE fused closure kernel per step
+    assert "x read once" in rec["roofline"]["kernel"] and rec["roofline"]["bytes_per_point"] == 40
 
 
 @pytest.mark.parametrize("d,order,fl,K,n", [(2, 2, 2, 10, 20000), (2, 3, 0, 3, 4097), (3, 2, 0, 5, 3001), (1, 4, 1, 16, 1000), (2, 5, 0, 20, 2500),
