@@ -21,7 +21,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write2 -- python3 "$R
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ops -- python3 "$R/tools/kbench.py" --table --S 1 --N 67108864 --libs 3:0,2:2 --reps 3 > "$O/${TAG}_ops_roofline.md" 2>/dev/null && echo "ops done"
 # VALU counters of the arithmetic-bound kernels, MFMA counters of the Gram
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_valu -- python3 "$R/tools/kbench.py" --table --S 1 --N 67108864 --libs 3:0 --reps 1 --only euler_jvp euler_jvp_vjp odeint odeint_rk4 symreg_linear loss_grad symreg_reversed > /dev/null 2>&1 && echo "valu done"
+export SYMODE_GRAM_VALU=0      # order 3 (F = 12) takes the vector-pipe Gram by default: this pass records the MFMA form it replaced
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma3 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 3 --reps 3 > /dev/null 2>&1
+unset SYMODE_GRAM_VALU
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_gvalu -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 3 --reps 3 > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 3 > /dev/null 2>&1 && echo "mfma done"
 cd "$R"
 python tools/rocprof_summary.py /tmp/prof_bench > "$O/${TAG}_bench_kernel_stats.txt"
@@ -30,6 +33,7 @@ python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024000000 "closure_re
 python tools/pmc_traffic.py /tmp/pmc_fetch2 /tmp/pmc_write2 1024000000 loss_grad=loss_grad_kernel "symreg_reversed=symreg_reversed_kernel<symode::Library<2, 5, 0>, false>" > "$O/pmc_traffic_two_launch.json"
 python tools/pmc_valu.py /tmp/pmc_valu euler_jvp_kernel euler_jvp_vjp_kernel odeint_kernel symreg_linear_kernel loss_grad_kernel symreg_reversed_kernel > "$O/${TAG}_valu_pmc.json"
 python tools/pmc_mfma.py /tmp/pmc_mfma3 aug_gram_kernel > "$O/${TAG}_gram_o3_mfma_pmc.json"
+python tools/pmc_valu.py /tmp/pmc_gvalu aug_gram_valu_kernel > "$O/${TAG}_gram_o3_valu_pmc.json"
 python tools/pmc_mfma.py /tmp/pmc_mfma5 aug_gram_kernel > "$O/${TAG}_gram_o5_mfma_pmc.json"
 python tools/latency_bench.py --orders 3 5 > "$O/${TAG}_latency.txt" 2>&1
 head -6 "$O/${TAG}_bench_kernel_stats.txt"
