@@ -45,6 +45,11 @@ class BatchedClosure:
         bounds = torch.linspace(0, self.S, self.n_chunks + 1).long().tolist()
         self.chunks = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
         self.buffers = [torch.empty((b - a) * nacc, dtype=torch.float32, device=x.device) for a, b in self.chunks]
+        # private scratch: a captured HIP graph (sweep.BatchedLBFGS) replays these launches from its own stream
+        self._ws_kw = {}
+        if x.is_cuda and hasattr(self.engine, 'new_workspace'):
+            self._ws_kw = {'ws': self.engine.new_workspace(x.device, self.engine.lib.symode_workspace_bytes(
+                self.d, poly_order, self.flags, max(b - a for a, b in self.chunks), self.n_local))}
         self.sym = None
         if reversed_sym is not None:
             gx, jgx, weight = reversed_sym
@@ -89,13 +94,13 @@ class BatchedClosure:
                 l2 = sb[:2 * n].view(n, 2)
                 self.engine.loss_grad_reversed(self.x[a:b], self.dx[a:b], gx[a:b], jgx[a:b], Xi[a:b],
                                                None if mask is None else mask[a:b], self.order, self.flags, w_sym=weight,
-                                               inv_count=self.inv_count, out=(l2, grad))
+                                               inv_count=self.inv_count, out=(l2, grad), **self._ws_kw)
                 torch.add(l2[:, 0], l2[:, 1], alpha=weight, out=loss)
                 if self.distributed:
                     works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 continue
             l, g = self.engine.loss_grad(self.x[a:b], self.dx[a:b], Xi[a:b], None if mask is None else mask[a:b],
-                                         self.order, self.flags, inv_count=self.inv_count, out=(loss, grad))
+                                         self.order, self.flags, inv_count=self.inv_count, out=(loss, grad), **self._ws_kw)
             if l.data_ptr() != loss.data_ptr():          # an engine that does not write in place
                 loss.copy_(l)
                 grad.copy_(g)
@@ -104,7 +109,7 @@ class BatchedClosure:
                 sb = self.sym_buffers[ci]
                 sl, sg = sb[:n], sb[n:].view(n, self.d, self.p)
                 l2, g2 = self.engine.symreg_reversed(self.x[a:b], gx[a:b], jgx[a:b], Xi[a:b], None if mask is None else mask[a:b],
-                                                     self.order, self.flags, out=(sl, sg), inv_count=self.inv_count)
+                                                     self.order, self.flags, out=(sl, sg), inv_count=self.inv_count, **self._ws_kw)
                 if l2.data_ptr() != sl.data_ptr():
                     sl.copy_(l2)
                     sg.copy_(g2)

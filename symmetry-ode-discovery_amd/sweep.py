@@ -10,6 +10,8 @@ per thresholding pass.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -102,7 +104,8 @@ class BatchedLBFGS:
     problem (symode_lbfgs_direction), when the variables live on the GPU.
     """
 
-    def __init__(self, params, lr, max_iter=20, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, engine=None):
+    def __init__(self, params, lr, max_iter=20, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, engine=None,
+                 use_graph=False):
         self.P = params                                   # (S, n), updated in place
         S, n = params.shape
         self.lr, self.max_iter, self.tol_g, self.tol_c, self.H = lr, max_iter, tolerance_grad, tolerance_change, history_size
@@ -120,14 +123,20 @@ class BatchedLBFGS:
         self.prev_g = torch.zeros(S, n, device=dev, dtype=dt)
         self.prev_loss = torch.zeros(S, device=dev, dtype=dt)
         self._rows = torch.arange(S, device=dev)
+        self._loss = torch.zeros(S, device=dev, dtype=dt)              # closure values / gradients / live flags of the running step
+        self._g = torch.zeros(S, n, device=dev, dtype=dt)
+        self._act = torch.zeros(S, dtype=torch.bool, device=dev)
+        # HIP-graph replay of the inner iteration: GPU variables + the direction kernel (no host sync inside) only
+        self.use_graph = bool(use_graph and params.is_cuda and self.engine is not None)
+        self._graph, self._graph_closure, self._warm = None, None, 0
 
     def reset(self, which):
-        """Fresh optimiser for the selected problems (the reference re-creates LBFGS after thresholding)."""
-        z = torch.zeros_like(self.n_iter)
-        self.n_iter = torch.where(which, z, self.n_iter)
-        self.hist = torch.where(which, z, self.hist)
-        self.head = torch.where(which, z, self.head)
-        self.H_diag = torch.where(which, torch.ones_like(self.H_diag), self.H_diag)
+        """Fresh optimiser for the selected problems (the reference re-creates LBFGS after thresholding).  In place:
+        a captured iteration graph holds these buffers."""
+        self.n_iter.masked_fill_(which, 0)
+        self.hist.masked_fill_(which, 0)
+        self.head.masked_fill_(which, 0)
+        self.H_diag.masked_fill_(which, 1.0)
 
     def _direction(self, g):
         if self.engine is not None:
@@ -150,62 +159,92 @@ class BatchedLBFGS:
             r = r + self.old_stps[self._rows, slot] * ((al[:, k] - be) * live)[:, None]
         return r
 
+    def _iteration(self, closure, evaluate):
+        """One inner iteration of every problem on the persistent buffers (self.P, _loss, _g, _act and the optimiser
+        state): everything is updated in place, so the sequence of launches can be captured once and replayed."""
+        P, g, loss, act = self.P, self._g, self._loss, self._act
+        self.n_iter.add_(act.long())
+        first = act & (self.n_iter == 1)
+        upd = act & ~first
+        # ---- curvature memory (torch: "do lbfgs update (update memory)") -------------------
+        self.hist.masked_fill_(first, 0)
+        self.head.masked_fill_(first, 0)
+        self.H_diag.masked_fill_(first, 1.0)
+        y = g - self.prev_g
+        s = self.d * self.t[:, None]
+        ys = (y * s).sum(1)
+        mem = upd & (ys > 1e-10)
+        full = mem & (self.hist == self.H)
+        pos = torch.where(full, self.head, (self.head + self.hist) % self.H)      # overwrite the oldest when full
+        m3 = mem[:, None]
+        self.old_dirs[self._rows, pos] = torch.where(m3, y, self.old_dirs[self._rows, pos])
+        self.old_stps[self._rows, pos] = torch.where(m3, s, self.old_stps[self._rows, pos])
+        safe_ys = torch.where(mem, ys, torch.ones_like(ys))
+        self.ro[self._rows, pos] = torch.where(mem, 1.0 / safe_ys, self.ro[self._rows, pos])
+        self.head.copy_(torch.where(full, (self.head + 1) % self.H, self.head))
+        self.hist.copy_(torch.where(mem & ~full, self.hist + 1, self.hist))
+        yy = (y * y).sum(1)
+        self.H_diag.copy_(torch.where(mem, ys / torch.where(mem, yy, torch.ones_like(yy)), self.H_diag))
+        # ---- direction: empty history gives d = -g, as torch's first iteration -----------------
+        d_new = self._direction(g)
+        self.d.copy_(torch.where(act[:, None], d_new, self.d))
+        self.prev_g.copy_(torch.where(act[:, None], g, self.prev_g))
+        self.prev_loss.copy_(torch.where(act, loss, self.prev_loss))
+        # ---- step length ---------------------------------------------------------------------
+        t_first = torch.clamp(1.0 / g.abs().sum(1), max=1.0) * self.lr
+        t_new = torch.where(self.n_iter == 1, t_first, torch.full_like(t_first, self.lr))
+        self.t.copy_(torch.where(act, t_new, self.t))
+        gtd = (g * self.d).sum(1)
+        live = act & ~(gtd > -self.tol_c)                                  # directional derivative below tolerance
+        P.add_(torch.where(live, self.t, torch.zeros_like(self.t))[:, None] * self.d)
+        if evaluate:                                                       # (no re-evaluation on the last iteration)
+            nl, ng = closure(P)
+            loss.copy_(torch.where(live, nl, loss))
+            g.copy_(torch.where(live[:, None], ng, g))
+            stop = (g.abs().amax(1) <= self.tol_g) | ((self.d * self.t[:, None]).abs().amax(1) <= self.tol_c) \
+                | ((loss - self.prev_loss).abs() < self.tol_c)
+            live = live & ~stop
+        act.copy_(live)
+
+    def _iteration_replayed(self, closure):
+        """The iteration is ~60 small launches around one fused closure kernel: launch-bound.  After a few eager runs
+        (lazy initialisations done) it is captured ONCE in a HIP graph and replayed -- same kernels, same buffers."""
+        if self._graph is None or self._graph_closure is not closure:
+            if self._warm < 3 or (self._graph is not None and self._graph_closure is not closure):
+                self._warm += 1
+                return self._iteration(closure, True)
+            try:
+                torch.cuda.synchronize(self.P.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._iteration(closure, True)
+                self._graph, self._graph_closure = graph, closure
+            except Exception:                                              # pragma: no cover - depends on the runtime
+                self.use_graph = False
+                return self._iteration(closure, True)
+        self._graph.replay()
+
     @torch.no_grad()
     def step(self, closure, frozen=None):
         """closure(P) -> (loss (S,), grad (S, n)).  ``frozen`` (S,) bool: problems that must not move."""
-        P = self.P
-        loss, g = closure(P)
-        loss, g = loss.clone(), g.clone()
+        loss, g = closure(self.P)
+        self._loss.copy_(loss)
+        self._g.copy_(g)
         act = g.abs().amax(dim=1) > self.tol_g                              # optimality test
         if frozen is not None:
             act = act & ~frozen
-        one = torch.ones_like(self.n_iter)
+        self._act.copy_(act)
         for it in range(1, self.max_iter + 1):
-            self.n_iter = self.n_iter + act.long()
-            first = act & (self.n_iter == 1)
-            upd = act & ~first
-            # ---- curvature memory (torch: "do lbfgs update (update memory)") -------------------
-            self.hist = torch.where(first, torch.zeros_like(self.hist), self.hist)
-            self.head = torch.where(first, torch.zeros_like(self.head), self.head)
-            self.H_diag = torch.where(first, torch.ones_like(self.H_diag), self.H_diag)
-            y = g - self.prev_g
-            s = self.d * self.t[:, None]
-            ys = (y * s).sum(1)
-            mem = upd & (ys > 1e-10)
-            full = mem & (self.hist == self.H)
-            pos = torch.where(full, self.head, (self.head + self.hist) % self.H)      # overwrite the oldest when full
-            m3 = mem[:, None]
-            self.old_dirs[self._rows, pos] = torch.where(m3, y, self.old_dirs[self._rows, pos])
-            self.old_stps[self._rows, pos] = torch.where(m3, s, self.old_stps[self._rows, pos])
-            safe_ys = torch.where(mem, ys, torch.ones_like(ys))
-            self.ro[self._rows, pos] = torch.where(mem, 1.0 / safe_ys, self.ro[self._rows, pos])
-            self.head = torch.where(full, (self.head + one) % self.H, self.head)
-            self.hist = torch.where(mem & ~full, self.hist + one, self.hist)
-            yy = (y * y).sum(1)
-            self.H_diag = torch.where(mem, ys / torch.where(mem, yy, torch.ones_like(yy)), self.H_diag)
-            # ---- direction: empty history gives d = -g, as torch's first iteration -----------------
-            d_new = self._direction(g)
-            self.d = torch.where(act[:, None], d_new, self.d)
-            self.prev_g = torch.where(act[:, None], g, self.prev_g)
-            self.prev_loss = torch.where(act, loss, self.prev_loss)
-            # ---- step length ---------------------------------------------------------------------
-            t_first = torch.clamp(1.0 / g.abs().sum(1), max=1.0) * self.lr
-            t_new = torch.where(self.n_iter == 1, t_first, torch.full_like(t_first, self.lr))
-            self.t = torch.where(act, t_new, self.t)
-            gtd = (g * self.d).sum(1)
-            act = act & ~(gtd > -self.tol_c)                               # directional derivative below tolerance
-            P += torch.where(act, self.t, torch.zeros_like(self.t))[:, None] * self.d
-            if it == self.max_iter:                                        # no re-evaluation on the last iteration
+            if it == self.max_iter:
+                self._iteration(closure, False)
                 break
-            nl, ng = closure(P)
-            loss = torch.where(act, nl, loss)
-            g = torch.where(act[:, None], ng, g)
-            stop = (g.abs().amax(1) <= self.tol_g) | ((self.d * self.t[:, None]).abs().amax(1) <= self.tol_c) \
-                | ((loss - self.prev_loss).abs() < self.tol_c)
-            act = act & ~stop
-            if it % 5 == 0 and not bool(act.any()):                        # the only host sync, every 5th iteration
+            if self.use_graph:
+                self._iteration_replayed(closure)
+            else:
+                self._iteration(closure, True)
+            if it % 5 == 0 and not bool(self._act.any()):                   # the only host sync, every 5th iteration
                 break
-        return loss
+        return self._loss.clone()
 
 
 class SeedSweepLBFGS:
@@ -261,7 +300,9 @@ class SeedSweepLBFGS:
         P = P0.clone().contiguous()
         S = P.shape[0]
         self.mask = torch.ones(S, c.d, c.p, device=P.device) if mask0 is None else mask0.clone()
-        opt = BatchedLBFGS(P, self.lr, engine=getattr(c, 'engine', None) if P.is_cuda else None)
+        graph_ok = P.is_cuda and not getattr(c, 'distributed', False) and os.environ.get('SYMODE_SWEEP_GRAPH', '1') != '0'
+        opt = BatchedLBFGS(P, self.lr, engine=getattr(c, 'engine', None) if P.is_cuda else None, use_graph=graph_ok)
+        closure = self._closure                               # ONE bound-method object: the captured graph is tied to it
         prev, pprev = P.clone(), P.clone()
         n_iters = torch.zeros(S, dtype=torch.long, device=P.device)
         done = torch.zeros(S, dtype=torch.bool, device=P.device)
@@ -274,7 +315,7 @@ class SeedSweepLBFGS:
             live = ~done
             n_iters = n_iters + live.long()
             epochs = torch.where(live, torch.full_like(epochs, epoch + 1), epochs)
-            opt.step(self._closure, frozen=done)
+            opt.step(closure, frozen=done)
             bad = live & torch.isnan(P).any(dim=1)                         # train.py:697-699
             nan |= bad
             done |= bad
@@ -290,7 +331,8 @@ class SeedSweepLBFGS:
             new_mask = torch.logical_and(Xi.abs() > self.threshold, self.mask > 0).float()
             close = ((Xi.abs() - self.threshold).abs() < NEAR_THRESHOLD_BAND) & (self.mask > 0)
             near = near + torch.where(ev, close.sum(dim=(1, 2)), torch.zeros_like(near))
-            self.mask = torch.where(ev[:, None, None], new_mask, self.mask)   # strict >, monotone (sindy.py:194)
+            self.mask.copy_(torch.where(ev[:, None, None], new_mask, self.mask))   # strict >, monotone (sindy.py:194); in place:
+            #                                                                       the captured iteration reads this buffer
             opt.reset(ev)
             n_iters = torch.where(ev, torch.zeros_like(n_iters), n_iters)
             pprev = torch.where(thr_conv[:, None], P, pprev)               # only on convergence-triggered events (:718)

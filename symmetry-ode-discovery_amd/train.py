@@ -322,8 +322,14 @@ class _HostShadow:
         # ONE launch + one stream sync (the last workgroup finalises inside the launch) -- no copy nodes, no graph.
         # Checked once against the copy path; any failure or difference leaves the copy path (+ HIP graph) in place.
         self.zero_copy = False
+        self._bound = self._bound_fused = None
+        self._stream = torch.cuda.current_stream(dev) if x.is_cuda else None
         if zero_copy and self.ws is not None:
             self.zero_copy = self._zero_copy_works()
+        if self.zero_copy and hasattr(eng, 'bind_closure'):
+            # all argument checks / conversions done once: the per-closure host cost is one ctypes call + one sync
+            self._bound = eng.bind_closure(x, dx, self.h_xi, regressor.mask, regressor.poly_order, regressor.flags,
+                                           (self.h_out[:1], self.h_out[1:self.n_out].view(d, p)), self.ws, self._stream)
         if not self.zero_copy and use_graph:
             self._capture()
 
@@ -346,9 +352,12 @@ class _HostShadow:
         Xi = self.get_Xi()
         self.h_xi.copy_(Xi.detach())
         gx, jgx = self.reversed_sym
-        reg.engine.loss_grad_reversed(self.x, self.dx, gx, jgx, self.h_xi, reg.mask, reg.poly_order, reg.flags, w_sym=w_ratio,
-                                      out=(self.h_out[:2], self.h_out[2:2 + d * p].view(d, p)), **self._kw())
-        torch.cuda.current_stream(self.x.device).synchronize()
+        if self._bound_fused is None or self._bound_fused[0] != w_ratio:
+            self._bound_fused = (w_ratio, reg.engine.bind_closure(
+                self.x, self.dx, self.h_xi, reg.mask, reg.poly_order, reg.flags, (self.h_out[:2], self.h_out[2:2 + d * p].view(d, p)),
+                self.ws, self._stream, reversed_sym=(gx, jgx), w_sym=w_ratio))
+        self._bound_fused[1]()
+        self._stream.synchronize()
         return Xi, self.h_out[0].clone(), self.h_out[1].clone(), self.h_out[2:2 + d * p].view(d, p).clone()
 
     def _zero_copy_works(self):
@@ -440,13 +449,17 @@ class _HostShadow:
         Xi = self.get_Xi()
         self.h_xi.copy_(Xi.detach())
         n = self.n_out
-        if self.zero_copy:
-            self._launch_zero_copy()
-        elif self._graph is not None:
-            self._graph.replay()
+        if self._bound is not None and self.reversed_sym is None:
+            self._bound()
+            self._stream.synchronize()
         else:
-            self._launch()
-        torch.cuda.current_stream(self.x.device).synchronize()
+            if self.zero_copy:
+                self._launch_zero_copy()
+            elif self._graph is not None:
+                self._graph.replay()
+            else:
+                self._launch()
+            torch.cuda.current_stream(self.x.device).synchronize()
         vals = [self.h_out[k * n].clone() for k in range(len(self.h_out) // n)]
         grads = [self.h_out[k * n + 1:(k + 1) * n].view(d, p).clone() for k in range(len(self.h_out) // n)]
         return Xi, vals, grads
