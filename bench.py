@@ -67,15 +67,21 @@ def parse(argv=None):
     ap.add_argument("--profile", action="store_true",
                     help="profiling run: only the batched steps (no legs, no single-problem loop, no CPU baseline), so that "
                          "rocprofv3 --stats averages the step's launches alone")
-    ap.add_argument("--master_port", type=int, default=29517)
+    ap.add_argument("--master_port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0 = pick a free one)")
     return ap.parse_args(argv)
 
 
 def spawn_ranks(a):
     """``python bench.py --gpus N`` with no torchrun environment: start N fresh rank processes (one per GPU) through
     torch.distributed.run and relay rank 0's JSON line.  This process never touches the GPU."""
+    port = a.master_port
+    if not port:                                       # back-to-back runs (N = 2, 4, 8) must not trip over a port in TIME_WAIT
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(a.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
@@ -208,7 +214,7 @@ def main():
     ranks_observed = 1
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.master_port), RANK="0", WORLD_SIZE="1")
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.master_port or 29517), RANK="0", WORLD_SIZE="1")
         with _StdoutToStderr():
             if a.rehearse_gloo:
                 dist.init_process_group("gloo")
