@@ -72,3 +72,101 @@ def test_gram_and_batched_loss_random(eng, lib, sine, exp, n, S, seed):
         wg = 2.0 / (n * d) * (W @ want[:p, :p] - want[:p, p:].T)
         assert np.isclose(loss[s].item(), wl.item(), rtol=1e-4, atol=1e-6)
         assert (grad[s].cpu().double() - wg).abs().max().item() <= 1e-4 * max(wg.abs().max().item(), 1e-6)
+
+
+@settings(**common)
+@given(lib=st.sampled_from(LIBS), sine=st.booleans(), exp=st.booleans(), n=st.integers(1, 1200), S=st.integers(1, 3), n_g=st.integers(1, 3),
+       seed=st.integers(0, 2 ** 20), use_mask=st.booleans(), w=st.floats(0.0, 2.0))
+def test_fused_closure_and_reversed_regulariser_random(eng, lib, sine, exp, n, S, n_g, seed, use_mask, w):
+    """symode_loss_grad_reversed / symode_symreg_reversed_batched over random libraries, sizes (ragged tails, one-point
+    problems), group-element counts and masks, against fp64 autograd through the oracle's op sequence."""
+    d, order = lib
+    fl = (1 if sine else 0) | (2 if exp else 0)
+    g = torch.Generator().manual_seed(seed)
+    p = O.term_count(d, order, sine, exp)
+    x, dx = torch.randn(S, n, d, generator=g) * 0.5, torch.randn(S, n, d, generator=g)
+    gx = x[:, None] + 0.05 * torch.randn(S, n_g, n, d, generator=g)
+    jgx = torch.eye(d) + 0.05 * torch.randn(S, n_g, n, d, d, generator=g)
+    Xi = torch.randn(S, d, p, generator=g) * 0.3
+    mask = (torch.rand(S, d, p, generator=g) > 0.3).float() if use_mask else torch.ones(S, d, p)
+    mg = mask.cuda() if use_mask else None
+    loss2, grad = eng.loss_grad_reversed(x.cuda(), dx.cuda(), gx.cuda(), jgx.cuda(), Xi.cuda(), mg, order, fl, w_sym=w)
+    ls, gs = eng.symreg_reversed(x.cuda(), gx.cuda(), jgx.cuda(), Xi.cuda(), mg, order, fl)
+    for s in range(S):
+        W = (Xi[s] * mask[s]).double().requires_grad_(True)
+        h = lambda a: O.theta(a.double(), order, sine, exp) @ W.T  # noqa: E731
+        hx = h(x[s])
+        mse = ((hx - dx[s].double()) ** 2).mean()
+        sym = sum(((torch.einsum("bij,bj->bi", jgx[s, k].double(), hx) - h(gx[s, k])) ** 2).mean() for k in range(n_g))
+        gm, = torch.autograd.grad(mse + w * sym, W, retain_graph=True)
+        gsym, = torch.autograd.grad(sym, W)
+        assert np.isclose(loss2[s, 0].item(), mse.item(), rtol=5e-5, atol=1e-9) and np.isclose(loss2[s, 1].item(), sym.item(), rtol=5e-5, atol=1e-9)
+        assert np.isclose(ls[s].item(), sym.item(), rtol=5e-5, atol=1e-9)
+        scale = max((gm * mask[s]).abs().max().item(), 1e-6)
+        assert (grad[s].cpu().double() - gm * mask[s]).abs().max().item() <= 5e-5 * scale
+        scale = max((gsym * mask[s]).abs().max().item(), 1e-6)
+        assert (gs[s].cpu().double() - gsym * mask[s]).abs().max().item() <= 5e-5 * scale
+
+
+@settings(**common)
+@given(lib=st.sampled_from(LIBS), sine=st.booleans(), exp=st.booleans(), T=st.integers(1, 700), K=st.integers(1, 40), off=st.integers(0, 3),
+       seed=st.integers(0, 2 ** 20))
+def test_weak_gram_random(eng, lib, sine, exp, T, K, off, seed):
+    d, order = lib
+    fl = (1 if sine else 0) | (2 if exp else 0)
+    g = torch.Generator().manual_seed(seed)
+    xa = torch.randn(T + off, d, generator=g) * 0.6
+    x = xa.cuda()[off:]                                            # off > 0: unaligned base
+    V, Vd = torch.randn(K, T, generator=g), torch.randn(K, T, generator=g)
+    G, b = eng.weak_gram(x, V.cuda(), Vd.cuda(), order, fl)
+    th = eng.theta(x, order, fl).cpu().double()
+    wG, wb = V.double() @ th, -(Vd.double() @ xa[off:].double())
+    assert torch.allclose(G.cpu(), wG, rtol=1e-11, atol=1e-11 * max(wG.abs().max().item(), 1e-30))
+    assert torch.allclose(b.cpu(), wb, rtol=1e-11, atol=1e-11 * max(wb.abs().max().item(), 1e-30))
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(lib=st.sampled_from(LIBS), sine=st.booleans(), exp=st.booleans(), n=st.integers(1, 900), K=st.integers(0, 24), off=st.integers(0, 3),
+       seed=st.integers(0, 2 ** 20))
+def test_streaming_maps_and_euler_pair_random(eng, lib, sine, exp, n, K, off, seed):
+    """forward_jvp / vjp / jvp_vjp / odeint / euler_jvp(+vjp): chunked 16-byte path, ragged tails and unaligned bases
+    against fp64 autograd through the oracle's forward; the Euler reverse sweep on both sides of its LDS-stack limit."""
+    d, order = lib
+    fl = (1 if sine else 0) | (2 if exp else 0)
+    gen = torch.Generator().manual_seed(seed)
+    p = O.term_count(d, order, sine, exp)
+    mk = lambda: (torch.randn(n + off, d, generator=gen) * 0.4)  # noqa: E731
+    xa, va, ga, ha = mk(), mk(), mk(), mk()
+    x, v, g1, g2 = (a.cuda()[off:] for a in (xa, va, ga, ha))
+    Xi = torch.randn(d, p, generator=gen) * 0.2
+    mask = (torch.rand(d, p, generator=gen) > 0.3).float()
+    W = (Xi * mask).double().requires_grad_(True)
+    X, Vv = xa[off:].double().requires_grad_(True), va[off:].double().requires_grad_(True)
+    f = lambda a: O.theta(a, order, sine, exp) @ W.T  # noqa: E731
+    out, jv = torch.autograd.functional.jvp(f, X, Vv, create_graph=True)
+    ((out * ga[off:].double()).sum() + (jv * ha[off:].double()).sum()).backward()
+    close = lambda got, want, tol=5e-5: (got.cpu().double() - want).abs().max().item() <= tol * max(want.abs().max().item(), 1e-6)  # noqa: E731
+    o2, j2 = eng.forward_jvp(x, v, Xi.cuda(), mask.cuda(), order, fl)
+    assert close(o2, out.detach()) and close(j2, jv.detach())
+    gx, gv, gxi = eng.jvp_vjp(x, v, g1, g2, Xi.cuda(), mask.cuda(), order, fl)
+    assert close(gx, X.grad) and close(gv, Vv.grad) and close(gxi, W.grad * mask.double())
+    gx1, gxi1 = eng.vjp(x, g1, Xi.cuda(), mask.cuda(), order, fl)
+    X2 = xa[off:].double().requires_grad_(True)
+    W2 = (Xi * mask).double().requires_grad_(True)
+    ((O.theta(X2, order, sine, exp) @ W2.T) * ga[off:].double()).sum().backward()
+    assert close(gx1, X2.grad) and close(gxi1, W2.grad * mask.double())
+    if K > 0:
+        dt = 0.01
+        X3, V3 = xa[off:].double().requires_grad_(True), va[off:].double().requires_grad_(True)
+        W3 = (Xi * mask).double().requires_grad_(True)
+        f3 = lambda a: O.theta(a, order, sine, exp) @ W3.T  # noqa: E731
+        xs, ts = X3, V3
+        for _ in range(K):
+            hh, jt = torch.autograd.functional.jvp(f3, xs, ts, create_graph=True)
+            xs, ts = xs + dt * hh, ts + dt * jt
+        ((xs * ga[off:].double()).sum() + (ts * ha[off:].double()).sum()).backward()
+        xo, to = eng.euler_jvp(x, v, Xi.cuda(), mask.cuda(), order, fl, K, dt)
+        assert close(xo, xs.detach(), 2e-5) and close(to, ts.detach(), 2e-5)
+        assert close(eng.odeint(x, Xi.cuda(), mask.cuda(), order, fl, K, dt), xs.detach(), 2e-5)
+        ex, ev, exi = eng.euler_jvp_vjp(x, v, g1, g2, Xi.cuda(), mask.cuda(), order, fl, K, dt)
+        assert close(ex, X3.grad, 1e-4) and close(ev, V3.grad, 1e-4) and close(exi, W3.grad * mask.double(), 1e-4)
