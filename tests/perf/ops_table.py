@@ -116,7 +116,7 @@ def main():
     add("odeint, 10 Euler steps, order 3", N, lambda: eng.odeint(x, Xi3g, None, 3, 0, 10, 0.01),
         lambda: O.odeint(lambda a: O.forward(a, Xi3, torch.ones(2, 10), 3), xc, 0.1 + 1e-9, 0.01))
 
-    print(f"# Per-operation timings, MI355X vs host CPU (round 1)\n")
+    print(f"# Per-operation timings, MI355X vs host CPU\n")
     print(f"Inputs: damped oscillator 50x2500x2 fp32 (N = {N} points) unless stated; GPU = HIP path through the C ABI "
           f"(wall time per call incl. Python + launch + sync, median of 50); CPU = oracle port of the reference op "
           f"sequence, torch {torch.__version__}, median of 20 on {threads} threads (box share; {os.cpu_count()} logical CPUs visible) "
