@@ -12,13 +12,15 @@ namespace {
 
 const LibOps* find_ops(int d, int order, int flags) {
     if (order < 1 || order > MAX_ORDER || flags < 0 || flags > 3) return nullptr;
-    switch (d) {
-        case 1: return ops_d1(order, flags);
-        case 2: return ops_d2(order, flags);
-        case 3: return ops_d3(order, flags);
-        case 4: return ops_d4(order, flags);
-        default: return nullptr;
+#define SYMODE_CASE(D, O) case D * 10 + O: return ops_d##D##_o##O(flags);
+    switch (d * 10 + order) {
+        SYMODE_CASE(1, 1) SYMODE_CASE(1, 2) SYMODE_CASE(1, 3) SYMODE_CASE(1, 4) SYMODE_CASE(1, 5)
+        SYMODE_CASE(2, 1) SYMODE_CASE(2, 2) SYMODE_CASE(2, 3) SYMODE_CASE(2, 4) SYMODE_CASE(2, 5)
+        SYMODE_CASE(3, 1) SYMODE_CASE(3, 2) SYMODE_CASE(3, 3) SYMODE_CASE(3, 4)
+        SYMODE_CASE(4, 1) SYMODE_CASE(4, 2) SYMODE_CASE(4, 3)
+        default: return nullptr;                      // (d, order) outside the compiled set
     }
+#undef SYMODE_CASE
 }
 
 inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p % a) != 0; }

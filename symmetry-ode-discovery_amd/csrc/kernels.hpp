@@ -1722,13 +1722,15 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     if (!TUNED && variant != 0) variant = 4;
     if constexpr (TUNED) {
         switch (variant) {
+#ifdef SYMODE_AB_VARIANTS        // the measured-and-rejected schedules (make AB=1; tools/ab_variants.py): not in the default build
             case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
             case 5: loss_grad_kernel<Lib, 5><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
             case 6: loss_grad_kernel<Lib, 6><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            case 7: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
             case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            default: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+#endif
+            case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            case 0: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
+            default: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
         }
     } else {
         if (variant == 4)

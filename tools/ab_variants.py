@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """A/B of SYMODE_LOSS_GRAD_VARIANT builds inside ONE gpurun call (box-to-box variance is ~10 %).
+Variants 2, 5, 6, 8 (measured and rejected in round 1, profiles/r01_ab_variants.txt) are compiled only by
+`make -C symmetry-ode-discovery_amd/csrc AB=1`; the default build holds 0, 4 and 7 (the default schedule).
 
 Each variant runs in its own child process (the variant is latched at first launch); every child
 times the batched closure and dumps loss/grad so the parent can check the variants agree bit for bit.
