@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--layers", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--cpu_reps", type=int, default=2)
+    ap.add_argument("--epochs", type=int, default=3, help="epochs (20 L-BFGS iterations each) of the end-to-end trainer timing")
     a = ap.parse_args()
     dev = "cuda:0"
     torch.manual_seed(0)
@@ -103,6 +104,32 @@ def main():
             tcs.append(time.perf_counter() - t0)
         tc = min(tcs)
         print(f"| {kind} | {tg*1e3:.2f} | {tc*1e3:.1f} | {tc/tg:.0f}x | {lg.item():.6f} | {lc.item():.6f} |")
+
+    # end to end: train_SIGED_lbfgs with each regulariser, L-BFGS variables on the host (default) vs on the device
+    import contextlib
+    import io
+    print()
+    print("| regulariser | epochs | trainer, host L-BFGS variables (s) | trainer, device variables (s) |")
+    print("|---|---|---|---|")
+    for kind in ("i", "f", "r"):
+        row = []
+        for host in (True, False):
+            for rep in range(2):                                  # first run warms up
+                rr = symode_amd.SINDyRegression(2, 2, False, True, threshold=0.15, device=dev)
+                rr.Xi.data = Xi0.to(dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    symode_amd.train.train_SIGED_lbfgs(
+                        train_loader=[(x, dx)], test_loader=[], num_epochs=a.epochs, device=dev, log_interval=10 ** 9, save_interval=10 ** 9,
+                        save_dir="symreg_tmp", autoencoder=ae, generator=gen, regressor=rr, regressor_dst=None, use_latent=False,
+                        distill_latent=False, lr_sindy=0.1, w_sindy_z=0.0, w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0,
+                        sym_reg_type=kind, w_sym_reg=0.1, st_freq=100, threshold=0.15, int_t=K * dt + 1e-9, int_dt=dt, print_eq=False,
+                        host_lbfgs=host)
+                torch.cuda.synchronize()
+                t = time.perf_counter() - t0
+            row.append(t)
+        print(f"| {kind} | {a.epochs} | {row[0]:.3f} | {row[1]:.3f} |")
 
 
 if __name__ == "__main__":

@@ -357,3 +357,26 @@ def test_constant_half_of_the_symmetry_regularisers_with_gradients(S, golden, ta
             out.append((loss.item(), r.Xi.grad.detach().cpu().clone()))
         assert out[1][0] == pytest.approx(out[0][0], rel=2e-5), kind
         assert (out[1][1] - out[0][1]).abs().max() <= 2e-4 * out[0][1].abs().max(), kind
+
+
+@pytest.mark.parametrize("sym", ["i", "f"])
+def test_host_resident_variables_for_autograd_closures(S, golden, sym, tmp_path, monkeypatch):
+    """train_SIGED_lbfgs with the infinitesimal / finite regulariser: L-BFGS variables on the host (closure on the device,
+    train._HostParams) vs on the device -- the same algorithm on the same closure: identical masks, close coefficients."""
+    monkeypatch.chdir(tmp_path)
+    g = golden("f6_symreg")
+    tag, act, rep = "relu_sim2", "ReLU", "(2,sim2)"
+    ae = load_fixture_autoencoder(g, tag, act, DEV)
+    gen = load_fixture_generator(g, tag, rep, DEV)
+    d, order, sine, exp = [int(v) for v in g[f"{tag}_cfg"]]
+    x, Xi0 = t(g[f"{tag}_x"]), t(g[f"{tag}_Xi"])
+    dx = O.forward(x, Xi0 * 0.5, torch.ones_like(Xi0), order, bool(sine), bool(exp)).detach()
+    out = []
+    for host in (True, False):
+        r = S.SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.05, device=DEV)
+        r.Xi.data = Xi0.to(DEV)
+        S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ae, generator=gen, regressor=r,
+                                  **_train_kwargs(sym_reg_type=sym, w_sym_reg=0.1, num_epochs=3, host_lbfgs=host))
+        out.append((r.Xi.detach().cpu().numpy(), r.mask.cpu().numpy()))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.allclose(out[0][0], out[1][0], rtol=2e-2, atol=2e-3)      # two un-converged fp32 L-BFGS trajectories (host vs device arithmetic)
