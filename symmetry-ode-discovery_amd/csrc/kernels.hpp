@@ -920,14 +920,13 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
                     acc[1 + j * P + k] = fmaf(u[j], dth[k], fmaf(-ltu[j], th[k], acc[1 + j * P + k]));
         }
     };
-    struct Ops {
-        float z[PPT][D];
-    };
-    for_each_chunk2<D, BLOCK, Ops, 4>(                     // one 16-byte load per chunk, ~120 VALU ops per point: four in flight
-        N, vec, [&](long c, Ops& o) { load_chunk<D>(z, c, o.z); },
-        [&](long c, Ops& o) {
+    for_each_point<D, BLOCK>(
+        N, vec,
+        [&](long c) {
+            float zp[PPT][D];
+            load_chunk<D>(z, c, zp);
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) one(o.z[i]);
+            for (int i = 0; i < PPT; ++i) one(zp[i]);
         },
         [&](long n) {
             float zp[D];

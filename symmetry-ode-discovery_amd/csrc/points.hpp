@@ -216,10 +216,7 @@ __device__ __forceinline__ void for_each_point(long N, bool vec, ChunkBody chunk
 // requested (load(c, ops): 16-byte non-temporal vectors through load_chunk) before either chunk is computed
 // (compute(c, ops)), so a lane keeps two chunks of every operand in flight; ragged tails and unaligned bases go
 // point by point.  Ops is the caller's bundle of per-chunk operand registers.
-// U = 4: four chunks in flight -- for kernels that read ONE small operand per point (8 bytes at D = 2) and spend a hundred
-// VALU ops on it, where two 16-byte loads per lane do not cover the memory latency; for the maps that also write their
-// results it measured slower than U = 2 (profiles/r02_pipeline_depth_ab.txt).
-template <int D, int BLOCK, class Ops, int U = 2, typename Load, typename Compute, typename PointBody>
+template <int D, int BLOCK, class Ops, typename Load, typename Compute, typename PointBody>
 __device__ __forceinline__ void for_each_chunk2(long N, bool vec, Load load, Compute compute, PointBody point_body) {
     constexpr int PPT = Chunk<D>::PPT;
     const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
@@ -227,19 +224,6 @@ __device__ __forceinline__ void for_each_chunk2(long N, bool vec, Load load, Com
     if (vec) {
         const long nchunks = N / PPT;
         long c = tid;
-        if constexpr (U == 4) {
-            for (; c + 3 * nthreads < nchunks; c += 4 * nthreads) {
-                Ops a, b, e, f;
-                load(c, a);
-                load(c + nthreads, b);
-                load(c + 2 * nthreads, e);
-                load(c + 3 * nthreads, f);
-                compute(c, a);
-                compute(c + nthreads, b);
-                compute(c + 2 * nthreads, e);
-                compute(c + 3 * nthreads, f);
-            }
-        }
         for (; c + nthreads < nchunks; c += 2 * nthreads) {
             Ops a, b;
             load(c, a);
