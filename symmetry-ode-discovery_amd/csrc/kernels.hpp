@@ -879,13 +879,20 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
 
+    // the first generator is read ONCE (uniform -> scalar registers): with one generator -- every fixed group of the
+    // reference, a single learned channel -- no scalar load is left inside the point loop
+    float L0[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) L0[a][b] = n_gen > 0 ? Lg[a * D + b] : 0.0f;
     auto one = [&](const float (&zp)[D]) {
         for (int g = 0; g < n_gen; ++g) {
             float L[D][D];
 #pragma unroll
             for (int a = 0; a < D; ++a)
 #pragma unroll
-                for (int b = 0; b < D; ++b) L[a][b] = Lg[(g * D + a) * D + b];
+                for (int b = 0; b < D; ++b) L[a][b] = (g == 0) ? L0[a][b] : Lg[(g * D + a) * D + b];
             float v[D];
 #pragma unroll
             for (int a = 0; a < D; ++a) {

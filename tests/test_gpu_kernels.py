@@ -654,3 +654,34 @@ def test_fused_closure_mse_plus_reversed_regulariser(eng, S, n, n_g, d, order, f
         (mse + w * sym).backward()
         assert np.isclose(loss2[s, 0].item(), mse.item(), rtol=2e-5) and np.isclose(loss2[s, 1].item(), sym.item(), rtol=2e-5)
         assert_close_scaled(grad[s].cpu(), reg.Xi.grad * mask[s], 3e-5, f"fused closure grad, problem {s}")
+
+
+def test_ticket_handoff_under_uneven_load_every_word(eng):
+    """The one-launch finalisation hands partial rows across workgroups without fences (write-through stores, drained,
+    one ticket add per workgroup, L1-bypassing loads).  Hammer it the way such hand-offs fail when they fail: thousands
+    of launches on ONE workspace whose partial rows change every launch (two alternating coefficient sets, so a stale row
+    from the previous launch would change the result), several grid shapes, a second stream keeping the memory system
+    busy -- every output word compared bit for bit with the two-launch form."""
+    torch.manual_seed(5)
+    cases = [(1, 125000, 2, 5), (1, 20000, 2, 3), (16, 9000, 2, 3), (1, 700000, 2, 2)]
+    side = torch.cuda.Stream()
+    big_a = torch.randn(1 << 26, device="cuda")
+    big_b = torch.empty_like(big_a)
+    for S, n, d, order in cases:
+        p = eng.lib_size(d, order, 0)
+        x, dx = (torch.randn(S, n, d) * 0.7).cuda(), torch.randn(S, n, d).cuda()
+        xis = [(torch.randn(S, d, p) * 0.3).cuda() for _ in range(2)]
+        with _env(SYMODE_FUSED_FINALIZE=0):
+            want = [tuple(t_.clone() for t_ in eng.loss_grad(x, dx, xi, None, order)) for xi in xis]
+        outs = [(torch.empty(S, device="cuda"), torch.empty(S, d, p, device="cuda")) for _ in range(2)]
+        bad = torch.zeros((), dtype=torch.int64, device="cuda")
+        with _env(SYMODE_FUSED_FINALIZE=1):
+            for it in range(1500):
+                if it % 50 == 0:                           # uneven background load from another stream
+                    with torch.cuda.stream(side):
+                        big_b.copy_(big_a)
+                k = it & 1
+                eng.loss_grad(x, dx, xis[k], None, order, out=outs[k])
+                bad += (outs[k][0] != want[k][0]).sum() + (outs[k][1] != want[k][1]).sum()
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0, (S, n, order, int(bad.item()))
