@@ -88,6 +88,7 @@ def test_symmetry_regularisers_match_reference(S, golden, tag, act, rep):
 
     def check(name, loss, grad, rl=2e-4, rg=2e-3):
         wl, wg = float(g[f"{tag}_{name}_loss"]), g[f"{tag}_{name}_grad"]
+        print(f"{tag} {name}: loss rel err {abs(loss - wl) / abs(wl):.2e}, grad scaled err {np.abs(grad - wg).max() / np.abs(wg).max():.2e}")
         assert np.isclose(loss, wl, rtol=rl), (name, loss, wl)
         assert np.abs(grad - wg).max() <= rg * np.abs(wg).max(), (name, np.abs(grad - wg).max() / np.abs(wg).max())
 

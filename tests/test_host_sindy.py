@@ -92,6 +92,17 @@ def test_constraint_order5_so2_is_equivariant():
     assert torch.allclose(jv, th @ M.T, atol=1e-10)
     Q, uk = constraint.constraint_Q([L], 2, 5)
     assert uk is True and Q.shape[0] == 42 and Q.shape[1] == 6      # a, b for degrees 1, 3, 5
+    # ... and the builder is complete and sound on its own terms, with no reference run to lean on: so(2)-equivariant
+    # polynomial fields of degree <= 5 are z g(|z|^2) with a complex quadratic g -- 6 real parameters = the 6 columns --
+    # and EVERY field in the span of Q satisfies J_h(x) L x = L h(x) (checked on random coefficients and points)
+    assert np.linalg.matrix_rank(Q.numpy()) == 6
+    for _ in range(4):
+        Xi = (Q.double() @ torch.randn(6, dtype=torch.float64)).view(2, -1)
+        h = lambda a: O.theta(a, 5) @ Xi.T  # noqa: E731
+        hz, jv = torch.autograd.functional.jvp(h, z, z @ L.double().T)
+        assert (jv - hz @ L.double().T).abs().max() <= 1e-5 * hz.abs().max()      # Q is fp32 (the null space of an fp32 SVD)
+    for order, want in ((1, 2), (2, 2), (3, 4), (4, 4)):            # degrees 1 | 1 | 1, 3 | 1, 3
+        assert constraint.constraint_Q([L], 2, order)[0].shape[1] == want
 
 
 # -------------------------------------------------------------------------- lstsq emulation
