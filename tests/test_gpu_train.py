@@ -86,7 +86,7 @@ def test_symmetry_regularisers_match_reference(S, golden, tag, act, rep):
         loss.backward()
         return loss.item(), r.Xi.grad.detach().cpu().numpy()
 
-    def check(name, loss, grad, rl=2e-4, rg=2e-3):
+    def check(name, loss, grad, rl=1e-5, rg=2e-5):          # measured on MI355X: <= 1.0e-6 / 1.1e-6 over both fixtures
         wl, wg = float(g[f"{tag}_{name}_loss"]), g[f"{tag}_{name}_grad"]
         print(f"{tag} {name}: loss rel err {abs(loss - wl) / abs(wl):.2e}, grad scaled err {np.abs(grad - wg).max() / np.abs(wg).max():.2e}")
         assert np.isclose(loss, wl, rtol=rl), (name, loss, wl)
@@ -98,9 +98,9 @@ def test_symmetry_regularisers_match_reference(S, golden, tag, act, rep):
     s3 = MU.make_fsymmreg_pttrain(ae, gen)
     check("s3", *run(lambda: s3(torch.stack([x, flow(x)], dim=1), f=flow)))
     s4 = MU.make_rsymmreg_pttrain(ae, gen)
-    check("s4", *run(lambda: s4(x, h=r)), rl=1e-3, rg=5e-3)                  # fused kernel on precomputed (g(x), J_g)
+    check("s4", *run(lambda: s4(x, h=r)))                                    # fused kernel on precomputed (g(x), J_g)
     basis = gen.get_full_basis_list()
-    check("s1", *run(lambda: MU.symmreg_linear(x, r, basis)), rl=1e-4, rg=1e-3)
+    check("s1", *run(lambda: MU.symmreg_linear(x, r, basis)))
 
 
 def test_forward_and_jvp_gradients_vs_fp64_double_backward(S):
