@@ -69,6 +69,46 @@ def test_config1_dosc_order5_equivariant_so2(S, tmp_path, monkeypatch):
     assert np.allclose(got[:, 1:3], [[-0.1, -1.0], [1.0, -0.1]], atol=2e-3)
 
 
+def test_config1_closure_along_the_oracle_trajectory_full_size(S):
+    """configs[1] at full size (50 x 2500 points, order 5, so2-constrained): every closure point of the oracle's own
+    L-BFGS run -- beta, const, mask from the random start to the converged sparse model -- evaluated by ONE batched launch
+    of the fused kernel: loss within 1e-5, gradient within 1e-5 of the magnitude of its operands (the yardstick of
+    tests/test_gpu_parity_round2.py), and the gradient w.r.t. (beta, const) through the product's Q within 2e-5."""
+    x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=0.0, seed=0, device=DEV)
+    x, dx = x[0], dx[0]
+    so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
+    torch.manual_seed(1)
+    r = S.SINDyRegression(2, 5, False, False, L_list=[so2], threshold=0.01, device=DEV, constrain_constant=False)
+
+    class Rec(O.OracleRegressor):
+        def __call__(self, a):
+            self.trace.append((self.get_Xi().detach().clone(), self.mask.clone()))
+            return super().__call__(a)
+    reg = Rec(2, 5, L_list=[so2], threshold=0.01, beta0=r.beta.detach().cpu(), const0=r.const.detach().cpu())
+    reg.Q = r.Q.cpu()
+    reg.trace = []
+    xc, dxc = x.cpu(), dx.cpu()
+    O.lbfgs_fit(reg, xc, dxc, 60, 1.0, st_freq=100, threshold=0.01)
+    trace = reg.trace[:: max(1, len(reg.trace) // 96)]                       # <= ~100 points spread over the run
+    n = len(trace)
+    assert n >= 20
+    Xi = torch.stack([a for a, _ in trace]).to(DEV)
+    M = torch.stack([b for _, b in trace]).to(DEV)
+    loss, grad = S.get_engine().loss_grad(x[None].expand(n, -1, -1).contiguous(), dx[None].expand(n, -1, -1).contiguous(), Xi, M, 5)
+    loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
+    th = O.theta(xc, 5).double().abs()
+    worst_l = worst_g = 0.0
+    for k, (a, b) in enumerate(trace):
+        wl, wg = O.mse_loss_and_grad(xc, dxc, a, b, 5)
+        operands = th @ (a * b).double().abs().T + dxc.double().abs()
+        yard = (2.0 / operands.numel()) * (operands.T @ th).numpy()
+        live = b.numpy() > 0
+        worst_l = max(worst_l, abs(loss[k] - wl.item()) / max(abs(wl.item()), 1e-7))
+        worst_g = max(worst_g, (np.abs(grad[k] - wg.numpy())[live] / yard[live]).max())
+    print(f"config1 full size: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad err vs operand magnitude {worst_g:.2e}")
+    assert worst_l <= 1e-5 and worst_g <= 1e-5, (worst_l, worst_g)
+
+
 def test_config3_selkov_64_seed_sweep_full_size(S):
     """configs[3]: selkov n_ics=10 x 10^4 steps, order 3, 64 seeds x 50 % subsamples, STLSQ (gamma 0, thr 7.5e-2)."""
     x, dx = S.data.make_dataset("selkov", 10, 10000, dt=0.002, noise=0.0, seed=2, device=DEV)
@@ -88,6 +128,15 @@ def test_config3_selkov_64_seed_sweep_full_size(S):
     Xi2, mask2, _ = sw.solve(0.0, 0.075, lstsq_driver="gels")
     assert all(np.array_equal(mask2[s].numpy() != 0, O.SINDY_TRUTH["selkov"] != 0) for s in range(64))
     assert np.allclose(Xi2.numpy(), np.broadcast_to(O.SINDY_TRUTH["selkov"], (64, 2, 10)), atol=2e-3)
+    # the full-rank solve against an fp64 QR of the same rows on the final support: the Gram route (cond 9e3, squared in the
+    # normal equations, fp64 throughout) keeps rtol 1e-5 with four digits to spare
+    th64 = O.theta(xc, 3).double()
+    for s in (0, 31, 63):
+        rows = sw.idx[s].long().cpu()
+        for j in range(2):
+            sup = mask2[s, j].numpy() != 0
+            w, *_ = np.linalg.lstsq(th64[rows][:, sup].numpy(), dxc[rows, j].double().numpy(), rcond=None)
+            assert np.allclose(Xi2[s, j].numpy()[sup], w, rtol=1e-5, atol=1e-7), (s, j)
 
 
 def test_config2_lv_exp_library_symreg_reversed_closure(S):
