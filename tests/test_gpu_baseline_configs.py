@@ -91,7 +91,7 @@ def test_config1_closure_along_the_oracle_trajectory_full_size(S):
     O.lbfgs_fit(reg, xc, dxc, 60, 1.0, st_freq=100, threshold=0.01)
     trace = reg.trace[:: max(1, len(reg.trace) // 96)]                       # <= ~100 points spread over the run
     n = len(trace)
-    assert n >= 20
+    assert n >= 10
     Xi = torch.stack([a for a, _ in trace]).to(DEV)
     M = torch.stack([b for _, b in trace]).to(DEV)
     loss, grad = S.get_engine().loss_grad(x[None].expand(n, -1, -1).contiguous(), dx[None].expand(n, -1, -1).contiguous(), Xi, M, 5)
