@@ -72,8 +72,9 @@ def test_config1_dosc_order5_equivariant_so2(S, tmp_path, monkeypatch):
 def test_config1_closure_along_the_oracle_trajectory_full_size(S):
     """configs[1] at full size (50 x 2500 points, order 5, so2-constrained): every closure point of the oracle's own
     L-BFGS run -- beta, const, mask from the random start to the converged sparse model -- evaluated by ONE batched launch
-    of the fused kernel: loss within 1e-5, gradient within 1e-5 of the magnitude of its operands (the yardstick of
-    tests/test_gpu_parity_round2.py), and the gradient w.r.t. (beta, const) through the product's Q within 2e-5."""
+    of the fused kernel: loss within 1e-5 of the oracle's; gradient within 1e-5 of the magnitude of its operands (the
+    yardstick of tests/test_gpu_parity_round2.py) measured against the fp64 evaluation of the same fp32 library -- at
+    125 000 points the oracle's own fp32 matmul is 3e-5 away from that (it is compared too, at 1e-4)."""
     x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=0.0, seed=0, device=DEV)
     x, dx = x[0], dx[0]
     so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
@@ -96,17 +97,22 @@ def test_config1_closure_along_the_oracle_trajectory_full_size(S):
     M = torch.stack([b for _, b in trace]).to(DEV)
     loss, grad = S.get_engine().loss_grad(x[None].expand(n, -1, -1).contiguous(), dx[None].expand(n, -1, -1).contiguous(), Xi, M, 5)
     loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
-    th = O.theta(xc, 5).double().abs()
-    worst_l = worst_g = 0.0
+    th64 = O.theta(xc, 5).double()
+    th = th64.abs()
+    worst_l = worst_g = worst_o = 0.0
     for k, (a, b) in enumerate(trace):
         wl, wg = O.mse_loss_and_grad(xc, dxc, a, b, 5)
+        r64 = th64 @ (a * b).double().T - dxc.double()
+        g64 = ((2.0 / r64.numel()) * (r64.T @ th64) * b.double()).numpy()
         operands = th @ (a * b).double().abs().T + dxc.double().abs()
         yard = (2.0 / operands.numel()) * (operands.T @ th).numpy()
         live = b.numpy() > 0
         worst_l = max(worst_l, abs(loss[k] - wl.item()) / max(abs(wl.item()), 1e-7))
-        worst_g = max(worst_g, (np.abs(grad[k] - wg.numpy())[live] / yard[live]).max())
-    print(f"config1 full size: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad err vs operand magnitude {worst_g:.2e}")
-    assert worst_l <= 1e-5 and worst_g <= 1e-5, (worst_l, worst_g)
+        worst_g = max(worst_g, (np.abs(grad[k] - g64)[live] / yard[live]).max())
+        worst_o = max(worst_o, (np.abs(grad[k] - wg.numpy())[live] / yard[live]).max())
+    print(f"config1 full size: {n} closure points, worst loss rel err {worst_l:.2e}, worst grad err vs operand magnitude: "
+          f"{worst_g:.2e} against fp64, {worst_o:.2e} against the fp32 oracle")
+    assert worst_l <= 1e-5 and worst_g <= 1e-5 and worst_o <= 1e-4, (worst_l, worst_g, worst_o)
 
 
 def test_config3_selkov_64_seed_sweep_full_size(S):
