@@ -143,22 +143,35 @@ def _fmt(value):
     return str(value)
 
 
+# the parser's sections (parser_utils._MAIN_ARGS is declared in this order): one line of the file per section
+SECTIONS = [("task", "smoothing"), ("batch_size", "w_sym_reg"), ("latent_dim", "fix_laligan"), ("ae_arch", "batch_norm"),
+            ("repr", "keep_center"), ("use_original_x", "y_embed_dim"), ("include_sindy", "lstsq_driver"),
+            ("pysr_subsample", "pysr_symmreg"), ("gpu", "seed")]
+
+
 def render(settings):
-    """Flags in the parser's declaration order; store_true flags bare."""
+    """Flags in the parser's declaration order, one line per parser section (the file is split on whitespace, so the
+    line structure is free); store_true flags bare."""
     import symode_amd.parser_utils as P
     order = [e[0] for e in P._MAIN_ARGS]
     kinds = {e[0]: e[1] for e in P._MAIN_ARGS}
     unknown = set(settings) - set(order)
     assert not unknown, unknown
     lines = []
-    for name in order:
-        if name not in settings:
-            continue
-        if kinds[name] == P._FLAG:
-            assert settings[name] is True
-            lines.append(f"--{name}")
-        else:
-            lines.append(f"--{name} {_fmt(settings[name])}")
+    for first, last in SECTIONS:
+        toks = []
+        for name in order[order.index(first):order.index(last) + 1]:
+            if name not in settings:
+                continue
+            if kinds[name] == P._FLAG:
+                assert settings[name] is True
+                toks.append(f"--{name}")
+            else:
+                toks.append(f"--{name} {_fmt(settings[name])}")
+        if toks:
+            lines.append("  ".join(toks))
+    covered = [n for f, l in SECTIONS for n in order[order.index(f):order.index(l) + 1]]
+    assert sorted(covered) == sorted(order), "SECTIONS must cover every flag exactly once"
     return "\n".join(lines) + "\n"
 
 
