@@ -4,7 +4,7 @@ reference types (``--config dosc/noise20_sindy.cfg``, ``bash run_scripts/dosc_no
 
 The table below holds the EFFECTIVE settings of every experiment (SURVEY.md Appendix A + the reference's
 run_configs read as data: hyper-parameters, save-dir names); each file is emitted from it in this parser's own
-flag order, one ``--flag value`` per line -- the token format parser_utils.parse_config splits on whitespace
+flag order, one line per parser section -- parser_utils.parse_config splits the file on whitespace
 (reference parser_utils.py:183-186).  tests/test_host_train.py::test_reference_config_names_parse checks that
 every file parses back to its row.  Out of scope and not written: the PySR configs (``*_pysr*.cfg``).
 
