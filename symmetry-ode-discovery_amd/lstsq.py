@@ -218,6 +218,8 @@ def _singular_fallback(G, C, m_rows):
         warnings.warn("singular normal equations under the full-rank (gels) driver: minimum-norm solution returned instead",
                       RuntimeWarning)
         _warned_singular = True
+    if _native():                                   # same algorithm in the native host routine (~100x less Python)
+        return lstsq_normal(G, C, m_rows, "gelsy", SINGULAR_RCOND)
     return lstsq_normal_py(G, C, m_rows, "gelsy", SINGULAR_RCOND)
 
 
