@@ -167,7 +167,8 @@ class SINDyRegression(nn.Module):
             self.Xi = nn.Parameter(torch.randn(self.latent_dim, n_terms, device=device))
         self.mask = torch.ones_like(self.Xi, device=device)
         self._gram_cache = None
-        self.near_threshold = []          # one dict per near-threshold coefficient met at a thresholding event
+        self._near = []                   # one dict per near-threshold coefficient met at a thresholding event
+        self._near_pending = []           # device-side events not yet looked at (no host sync inside the solve loops)
 
     # ------------------------------------------------------------------ evaluation
     def _coef(self):
@@ -234,12 +235,34 @@ class SINDyRegression(nn.Module):
 
     # ------------------------------------------------------------------ sparsity
     def note_near_threshold(self, xi, mask, threshold, where=''):
+        """Record the coefficients within NEAR_THRESHOLD_BAND of ``threshold``.  Device tensors are only snapshotted here
+        (two tiny copies, no synchronisation: the latent solve runs this five times per batch) and examined when
+        ``near_threshold`` is read."""
+        if torch.is_tensor(xi) and xi.is_cuda:
+            self._near_pending.append((xi.detach().clone(), mask.detach().clone(), float(threshold), where))
+            if len(self._near_pending) > 256:
+                self._flush_near()
+            return
+        xi = xi.detach().cpu().numpy() if torch.is_tensor(xi) else xi
+        mask = mask.detach().cpu().numpy() if torch.is_tensor(mask) else mask
         for i, k, v in near_threshold_cases(xi, mask, threshold):
-            self.near_threshold.append({'where': where, 'threshold': float(threshold), 'index': (i, k), 'abs_coef': v})
+            self._near.append({'where': where, 'threshold': float(threshold), 'index': (i, k), 'abs_coef': v})
+
+    def _flush_near(self):
+        pending, self._near_pending = self._near_pending, []
+        for xi, mask, threshold, where in pending:
+            self.note_near_threshold(xi.cpu(), mask.cpu(), threshold, where)
+
+    @property
+    def near_threshold(self):
+        """[{'where', 'threshold', 'index': (row, col), 'abs_coef'}] for every coefficient that sat within 1e-4 of the
+        threshold at a thresholding event."""
+        self._flush_near()
+        return self._near
 
     def set_threshold(self, threshold):                                   # sindy.py:192-194 (strict >)
         self.Xi = self.get_Xi() if self.constraint else self.Xi
-        self.note_near_threshold(self.Xi.detach().cpu().numpy(), self.mask.cpu().numpy(), threshold, 'set_threshold')
+        self.note_near_threshold(self.Xi, self.mask, threshold, 'set_threshold')
         self.mask.data = torch.logical_and(torch.abs(self.Xi) > threshold, self.mask).float()
 
     def reset_mask(self):                                                 # sindy.py:197-198
