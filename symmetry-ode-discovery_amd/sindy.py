@@ -333,6 +333,34 @@ def stlsq_solve_from_gram(G, N, mask, gamma, d, driver="gelsy"):
     return Xi, yy - 2 * w @ cm + w @ Gm @ w
 
 
+def _mask_on_host(regressor):
+    """Boolean host copy of the mask without a device round trip when the mask on the device is still the tensor this
+    module uploaded last (the mirror keeps that tensor alive, so an equal address means the same storage; in-place
+    edits bump the version counter)."""
+    m = regressor.mask
+    c = getattr(regressor, '_mask_mirror', None)
+    if c is not None and c[0].data_ptr() == m.data_ptr() and c[1] == m._version and c[0].shape == m.shape:
+        return c[2]
+    host = (m > 0.0).cpu().numpy()
+    regressor._mask_mirror = None
+    return host
+
+
+def _upload_mask(regressor, new_mask):
+    t = torch.from_numpy(new_mask.astype(np.float32)).to(regressor.mask.device)
+    regressor.mask.data = t
+    regressor._mask_mirror = (t, regressor.mask._version, new_mask.copy())
+
+
+def _constraint_on_host(regressor):
+    """fp64 host copy of Q (d*p, r), refreshed when the regressor's Q tensor changes (update_Q)."""
+    c = getattr(regressor, '_q_mirror', None)
+    if c is None or c[0] is not regressor.Q or c[1] != regressor.Q._version:
+        c = (regressor.Q, regressor.Q._version, regressor.Q.detach().cpu().double().numpy())
+        regressor._q_mirror = c
+    return c[2]
+
+
 def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
     '''
     Solve  argmin_w ||y - w Theta(x)||^2 + w_sindy_reg^2 ||w||^2  on the current support, then
@@ -347,9 +375,10 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
     G = regressor.aug_gram(x, y)
     Gtt, Gty, yy, d, p = _normal_system(regressor, G, float(w_sindy_reg))
     driver = kwargs.get("lstsq_driver", regressor.lstsq_driver)
-    mask = (regressor.mask > 0.0).cpu().numpy()
+    mask = _mask_on_host(regressor)
     dev = regressor.mask.device
-    prev_mask = regressor.mask.clone()
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)
+    prev_mask = regressor.mask.clone() if needs_grad else None
 
     if mask.all() and not regressor.constraint:
         W, _ = lstsq_normal(Gtt, Gty, N + p, driver)                       # (p, d); sindy.py:288, 300
@@ -374,7 +403,7 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
             regressor.Xi.data = torch.from_numpy(xi_host.copy()).to(dev)
             residual = yy - 2 * w @ cm + w @ Gm @ w
         else:
-            Q = regressor.Q.detach().cpu().double().numpy()
+            Q = _constraint_on_host(regressor)
             if regressor.allow_constant:                                    # sindy.py:277-280
                 Q = np.concatenate([Q, np.zeros((Q.shape[0], d))], axis=1)
                 for i in range(d):
@@ -394,21 +423,23 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
                 regressor.beta.data = torch.from_numpy(full[:-d].copy()).float().to(dev)
                 regressor.const.data = torch.from_numpy(full[-d:].copy()).float().view(-1, 1).to(dev)
             residual = yy - 2 * b @ cq + b @ Gq @ b
-    needs_grad = torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)
+            # get_Xi of THIS solution on the host, in fp32 like the device product (sindy.py:169-176)
+            beta_h = (full[:-d] if regressor.allow_constant else full).astype(np.float32)
+            flat_xi = _constraint_on_host(regressor).astype(np.float32) @ beta_h
+            xi_host = flat_xi.reshape(d, p).copy() if regressor.use_kron_product else flat_xi.reshape(p, d).T.copy()
+            if regressor.allow_constant:
+                xi_host[:, 0] += full[-d:].astype(np.float32)
+            regressor.Xi = regressor.get_Xi()                               # as set_threshold leaves it (sindy.py:193)
     # coefficients of THIS solve (support = the mask it was solved on), before the new threshold is applied
     xi_sol = None
     if needs_grad:
         xi_sol = ((regressor.get_Xi() if regressor.constraint else regressor.Xi).detach() * prev_mask).contiguous()
-    if regressor.constraint:
-        regressor.set_threshold(st_threshold)                               # sindy.py:312 (Xi = Q beta is a device product)
-        converged = torch.allclose(prev_mask, regressor.mask)               # sindy.py:313
-    else:
-        # the solution was just made on the host: threshold it there (same fp32 values, same strict >, sindy.py:192-194)
-        # and upload the mask -- instead of three device launches and a synchronising allclose
-        regressor.note_near_threshold(xi_host, mask, st_threshold, 'solve_SINDy_one_step')
-        new_mask = np.logical_and(np.abs(xi_host) > np.float32(st_threshold), mask)
-        regressor.mask.data = torch.from_numpy(new_mask.astype(np.float32)).to(dev)
-        converged = bool(np.array_equal(new_mask, mask))
+    # The solution was just made on the host: threshold it there (same fp32 values, same strict >, sindy.py:192-194, 312)
+    # and upload the mask -- no device launches, no synchronising allclose (sindy.py:313), no mask download next pass.
+    regressor.note_near_threshold(xi_host, mask, st_threshold, 'solve_SINDy_one_step')
+    new_mask = np.logical_and(np.abs(xi_host) > np.float32(st_threshold), mask)
+    _upload_mask(regressor, new_mask)
+    converged = bool(np.array_equal(new_mask, mask))
     value = torch.tensor(residual / N, dtype=torch.float32, device=dev)
     if needs_grad:
         # lm.residuals is per right-hand side: d columns for the full-mask solve, one for the flattened system
