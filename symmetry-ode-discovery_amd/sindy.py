@@ -346,10 +346,23 @@ def _mask_on_host(regressor):
     return host
 
 
-def _upload_mask(regressor, new_mask):
-    t = torch.from_numpy(new_mask.astype(np.float32)).to(regressor.mask.device)
+def _upload_mask(regressor, new_mask, t=None):
+    if t is None:
+        t = torch.from_numpy(new_mask.astype(np.float32)).to(regressor.mask.device)
     regressor.mask.data = t
     regressor._mask_mirror = (t, regressor.mask._version, new_mask.copy())
+
+
+def _upload_packed(dev, *arrays):
+    """Several small host arrays to the device in ONE copy; returns fp32 device views of their shapes."""
+    flat = np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in arrays])
+    buf = torch.from_numpy(flat).to(dev)
+    out, off = [], 0
+    for a in arrays:
+        n = int(np.asarray(a).size)
+        out.append(buf[off:off + n].view(np.asarray(a).shape))
+        off += n
+    return out
 
 
 def _constraint_on_host(regressor):
@@ -380,11 +393,12 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)
     prev_mask = regressor.mask.clone() if needs_grad else None
 
+    uploads = {}                                                            # name -> host array: one packed copy at the end
     if mask.all() and not regressor.constraint:
         W, _ = lstsq_normal(Gtt, Gty, N + p, driver)                       # (p, d); sindy.py:288, 300
         res = np.array([G[p + j, p + j] - 2 * W[:, j] @ Gty[:, j] + W[:, j] @ Gtt @ W[:, j] for j in range(d)])
         xi_host = W.T.astype(np.float32)                                    # what .float() makes of it on the device
-        regressor.Xi.data = torch.from_numpy(xi_host.copy()).to(dev)
+        uploads['Xi'] = xi_host
         residual = res.mean()
     else:
         # block-diagonal system over all equations, equation-major flattening (sindy.py:270-274)
@@ -400,7 +414,7 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
             new_coef = np.zeros((d, p))
             new_coef[mask] = w                                              # sindy.py:296-298
             xi_host = new_coef.astype(np.float32)
-            regressor.Xi.data = torch.from_numpy(xi_host.copy()).to(dev)
+            uploads['Xi'] = xi_host
             residual = yy - 2 * w @ cm + w @ Gm @ w
         else:
             Q = _constraint_on_host(regressor)
@@ -418,10 +432,10 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
             full = np.zeros(Q.shape[1])
             full[effective] = b
             if not regressor.allow_constant:                                # sindy.py:302-305
-                regressor.beta.data = torch.from_numpy(full).float().to(dev)
+                uploads['beta'] = full.astype(np.float32)
             else:                                                           # sindy.py:307-311
-                regressor.beta.data = torch.from_numpy(full[:-d].copy()).float().to(dev)
-                regressor.const.data = torch.from_numpy(full[-d:].copy()).float().view(-1, 1).to(dev)
+                uploads['beta'] = full[:-d].astype(np.float32)
+                uploads['const'] = full[-d:].astype(np.float32).reshape(-1, 1)
             residual = yy - 2 * b @ cq + b @ Gq @ b
             # get_Xi of THIS solution on the host, in fp32 like the device product (sindy.py:169-176)
             beta_h = (full[:-d] if regressor.allow_constant else full).astype(np.float32)
@@ -429,18 +443,23 @@ def solve_SINDy_one_step(regressor, x, y, w_sindy_reg, st_threshold, **kwargs):
             xi_host = flat_xi.reshape(d, p).copy() if regressor.use_kron_product else flat_xi.reshape(p, d).T.copy()
             if regressor.allow_constant:
                 xi_host[:, 0] += full[-d:].astype(np.float32)
-            regressor.Xi = regressor.get_Xi()                               # as set_threshold leaves it (sindy.py:193)
-    # coefficients of THIS solve (support = the mask it was solved on), before the new threshold is applied
-    xi_sol = None
-    if needs_grad:
-        xi_sol = ((regressor.get_Xi() if regressor.constraint else regressor.Xi).detach() * prev_mask).contiguous()
-    # The solution was just made on the host: threshold it there (same fp32 values, same strict >, sindy.py:192-194, 312)
-    # and upload the mask -- no device launches, no synchronising allclose (sindy.py:313), no mask download next pass.
+    # The solution was made on the host: threshold it there too (same fp32 values, same strict >, sindy.py:192-194, 312),
+    # then ONE packed copy carries coefficients, mask and residual up -- no device launches, no synchronising allclose
+    # (sindy.py:313), no mask download on the next pass.
     regressor.note_near_threshold(xi_host, mask, st_threshold, 'solve_SINDy_one_step')
     new_mask = np.logical_and(np.abs(xi_host) > np.float32(st_threshold), mask)
-    _upload_mask(regressor, new_mask)
     converged = bool(np.array_equal(new_mask, mask))
-    value = torch.tensor(residual / N, dtype=torch.float32, device=dev)
+    names = list(uploads)
+    parts = _upload_packed(dev, *[uploads[k] for k in names], new_mask.astype(np.float32), np.float32(residual / N))
+    for k, t_dev in zip(names, parts):
+        getattr(regressor, k).data = t_dev
+    xi_sol = None
+    if needs_grad:       # coefficients of THIS solve on the support it was solved on, before the new threshold applies
+        xi_sol = ((regressor.get_Xi() if regressor.constraint else regressor.Xi).detach() * prev_mask).contiguous()
+    _upload_mask(regressor, new_mask, parts[len(names)])
+    if regressor.constraint:
+        regressor.Xi = regressor.get_Xi()                                   # as set_threshold leaves it (sindy.py:193)
+    value = parts[-1].reshape(())
     if needs_grad:
         # lm.residuals is per right-hand side: d columns for the full-mask solve, one for the flattened system
         per_col = mask.all() and not regressor.constraint
