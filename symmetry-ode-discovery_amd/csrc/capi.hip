@@ -61,6 +61,17 @@ inline int gram_valu_grid(long n, long S, int d) {
     return (int)g;
 }
 
+// One large problem through a reduction kernel: the workgroups loop over the data with a grid-wide stride, so all of
+// them read one moving window of memory -- and fewer, longer-lived workgroups keep that window (and the DRAM pages under
+// it) tighter.  Measured at 2^26 points, d = 2, order 3 (fraction of the HBM roof at 512 / 1024 / 2048 workgroups):
+// vjp without grad_x 0.82 / 0.77 / 0.63, jvp_vjp 0.67 / 0.60 / 0.61, symreg_reversed 0.33 / 0.78 / 0.75 (its 4 waves per
+// SIMD need 1024 to cover the latency).  SYMODE_REDUCE_GRID overrides every cap for tuning runs.
+inline int single_problem_grid(int gx, int cap) {
+    static const int env = getenv("SYMODE_REDUCE_GRID") ? atoi(getenv("SYMODE_REDUCE_GRID")) : 0;
+    const int c = env > 0 ? env : cap;
+    return gx > c ? c : gx;
+}
+
 // points per 16-byte chunk step (points.hpp, Chunk<D>::PPT)
 inline int ppt_for(int d) { return d == 2 ? 2 : d == 4 ? 1 : 4; }
 
@@ -214,7 +225,7 @@ int symode_symreg_linear(const float* z, long n, int d, int order, int flags, co
     if (!z || !xi || !loss_out || !grad_out || (n_gen > 0 && !L)) return SYMODE_E_NULLPTR;
     if (misaligned(z, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(L, 4)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = grid_x_for(n, 1, ppt_for(d));
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), 1024);
     return (int)ops->symreg_linear(z, n, xi, mask, L, n_gen, loss_out, grad_out, (double*)workspace, gx,
                                    (hipStream_t)stream);
 }
@@ -233,6 +244,8 @@ int symode_symreg_reversed_batched(const float* x, const float* gx_, const float
     if (n_problems == 1 && gx <= 512) {
         const int cap = small_grid_cap();
         if (cap > 0 && gx > cap) gx = cap;
+    } else if (n_problems == 1) {
+        gx = single_problem_grid(gx, 1024);
     }
     return (int)ops->symreg_reversed(x, nullptr, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, 1.0f, loss_out, grad_out,
                                      (double*)workspace, gx, (hipStream_t)stream);
@@ -252,6 +265,8 @@ int symode_loss_grad_reversed(const float* x, const float* dx, const float* gx_,
     if (n_problems == 1 && gx <= 512) {
         const int cap = small_grid_cap();
         if (cap > 0 && gx > cap) gx = cap;
+    } else if (n_problems == 1) {
+        gx = single_problem_grid(gx, 1024);
     }
     return (int)ops->symreg_reversed(x, dx, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, w_sym, loss2_out, grad_out,
                                      (double*)workspace, gx, (hipStream_t)stream);
@@ -290,7 +305,7 @@ int symode_vjp(const float* x, const float* g, long n, int d, int order, int fla
         misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = grid_x_for(n, 1, ppt_for(d));
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), grad_x ? 1024 : 512);
     return (int)ops->vjp(x, g, n, xi, mask, grad_x, grad_xi, (double*)workspace, gx, (hipStream_t)stream);
 }
 
@@ -316,7 +331,7 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
         misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = grid_x_for(n, 1, ppt_for(d));
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), 512);
     return (int)ops->jvp_vjp(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, grad_xi, (double*)workspace, gx,
                              (hipStream_t)stream);
 }
