@@ -69,6 +69,44 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.symode_workspace_bytes(9, 3, 0, 1, 125000) == 0
 
 
+def test_argument_validation_of_the_round2_entries(lib):
+    """Every entry added with ABI version 2 rejects bad sizes / null or misaligned pointers / short workspaces before it
+    touches the GPU (codes: -1 unsupported, -2 null, -3 size, -4 workspace, -5 alignment)."""
+    null = ctypes.c_void_p(None)
+    buf = (ctypes.c_double * 64)()
+    good = ctypes.cast(buf, ctypes.c_void_p)
+    odd = ctypes.c_void_p(ctypes.addressof(buf) + 2)
+    assert lib.symode_workspace_init(null, 1 << 20, null) == -2
+    assert lib.symode_workspace_init(odd, 1 << 20, null) == -5
+    assert lib.symode_workspace_init(good, 64, null) == -4             # shorter than the ticket header
+    # symreg_reversed_batched(x, gx, jgx, n_g, S, n, d, order, flags, xi, mask, inv_count, loss, grad, ws, ws_bytes, stream)
+    f = lib.symode_symreg_reversed_batched
+    assert f(good, good, good, 1, 1, 8, 9, 3, 0, good, null, 1.0, good, good, good, 512, null) == -1
+    assert f(good, good, good, 1, 0, 8, 2, 3, 0, good, null, 1.0, good, good, good, 512, null) == -3
+    assert f(good, good, good, 1, 65536, 8, 2, 3, 0, good, null, 1.0, good, good, good, 512, null) == -3
+    assert f(good, good, good, -1, 1, 8, 2, 3, 0, good, null, 1.0, good, good, good, 512, null) == -3
+    assert f(good, null, null, 1, 1, 8, 2, 3, 0, good, null, 1.0, good, good, good, 512, null) == -2
+    assert f(odd, good, good, 1, 1, 8, 2, 3, 0, good, null, 1.0, good, good, good, 512, null) == -5
+    assert f(good, good, good, 1, 1, 8, 2, 3, 0, good, null, 1.0, good, good, null, 0, null) == -4
+    assert f(good, good, good, 1, 1, 8, 2, 3, 0, good, null, 1.0, good, good, good, 512, null) == -4
+    # loss_grad_reversed(x, dx, gx, jgx, n_g, S, n, d, order, flags, xi, mask, inv_count, w_sym, loss2, grad, ws, ws_bytes, stream)
+    f = lib.symode_loss_grad_reversed
+    assert f(good, good, good, good, 1, 1, 8, 2, 6, 0, good, null, 1.0, 1.0, good, good, good, 512, null) == -1
+    assert f(good, good, good, good, 0, 1, 8, 2, 3, 0, good, null, 1.0, 1.0, good, good, good, 512, null) == -3    # needs a generator
+    assert f(good, good, good, good, 1, 1, 0, 2, 3, 0, good, null, 1.0, 1.0, good, good, good, 512, null) == -3
+    assert f(good, null, good, good, 1, 1, 8, 2, 3, 0, good, null, 1.0, 1.0, good, good, good, 512, null) == -2
+    assert f(good, good, good, good, 1, 1, 8, 2, 3, 0, good, odd, 1.0, 1.0, good, good, good, 512, null) == -5
+    assert f(good, good, good, good, 1, 1, 8, 2, 3, 0, good, null, 1.0, 1.0, good, good, good, 512, null) == -4
+    # weak_gram(x, n_t, d, order, flags, V, V_drv, n_test, out, ws, ws_bytes, stream)
+    f = lib.symode_weak_gram
+    assert f(good, 8, 2, 3, 4, good, good, 4, good, good, 512, null) == -1
+    assert f(good, 0, 2, 3, 0, good, good, 4, good, good, 512, null) == -3
+    assert f(good, 8, 2, 3, 0, good, good, 129, good, good, 512, null) == -3
+    assert f(good, 8, 2, 3, 0, good, null, 4, good, good, 512, null) == -2
+    assert f(good, 8, 2, 3, 0, good, good, 4, odd, good, 512, null) == -5
+    assert f(good, 8, 2, 3, 0, good, good, 4, good, good, 512, null) == -4
+
+
 def test_engine_refuses_cpu_tensors():
     import torch
     eng = symode_amd.get_engine()
