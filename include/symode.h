@@ -203,6 +203,27 @@ int symode_lbfgs_direction(const float* g, const float* old_dirs, const float* o
                            const long* head, const long* count, const float* h_diag, long n_problems, int n,
                            int history, float* d_out, void* stream);
 
+/* One inner iteration of torch.optim.LBFGS.step (no line search) for n_problems problems, up to and including the move
+ * x += t d: curvature-pair update of the ring buffers, two-loop recursion, step length (first iteration:
+ * min(1, 1/|g|_1) lr), directional-derivative test.  One wavefront per problem, one launch for everything
+ * torch/optim/lbfgs.py does between two closure evaluations.  State arrays as in symode_lbfgs_direction plus
+ * n_iter (S) int64, d / prev_g (S, n), t / prev_loss (S); act (S) bytes: in = problem is active, out = problem moved
+ * (its closure must be re-evaluated).  Inactive problems are left untouched.
+ * replaces: the body of torch.optim.LBFGS.step that train.py:630-695 runs per seed and per inner iteration. */
+int symode_lbfgs_update(float* params, const float* g, const float* loss, unsigned char* act, long* n_iter, float* d,
+                        float* t, float* old_dirs, float* old_stps, float* ro, long* head, long* count, float* h_diag,
+                        float* prev_g, float* prev_loss, long n_problems, int n, int history, float lr,
+                        float tol_change, void* stream);
+
+/* Second half of that iteration, after the closure was re-evaluated at the moved parameters: problems with act != 0
+ * take new_loss / new_g into loss / g and run the three stopping tests of torch/optim/lbfgs.py (max|g| <= tol_grad,
+ * max|t d| <= tol_change, |loss - prev_loss| < tol_change); act: in = moved, out = still active.
+ * params != NULL: new_loss / new_g are the bare data term and the objective is w_x * loss + w_reg * |params|_1 (the L1
+ * term over the raw parameters, train.py:680-688), gradient w_x * g + w_reg * sign(params), formed here. */
+int symode_lbfgs_accept(const float* new_loss, const float* new_g, float* loss, float* g, unsigned char* act, const float* d,
+                        const float* t, const float* prev_loss, long n_problems, int n, float tol_grad, float tol_change,
+                        const float* params, float w_x, float w_reg, void* stream);
+
 /* HOST function (no GPU work): least squares on the normal equations G = A^T A (n, n), C = A^T b (n, k), fp64
  * row-major host arrays; A had m_rows rows.  driver 0 = LAPACK gelsy semantics (pivoted QR rank rule with
  * rcond < 0 -> torch's default eps_fp32 * max(m_rows, n), minimum-norm solution), driver 1 = gels (full rank).

@@ -78,8 +78,9 @@ class BatchedClosure:
         return g_beta, g_const
 
     # -- the hot path -------------------------------------------------------------------------
-    def loss_grad_xi(self, Xi, mask=None):
-        """loss (S,), dloss/dXi (S, d, p) summed over all ranks' shards."""
+    def loss_grad_xi(self, Xi, mask=None, alias=False):
+        """loss (S,), dloss/dXi (S, d, p) summed over all ranks' shards.  ``alias=True``: with a single chunk the results
+        are returned as views of the packed buffer the kernel wrote (no copies; overwritten by the next evaluation)."""
         works = []
         fused = self.sym is not None and self.fuse_sym and hasattr(self.engine, 'loss_grad_reversed')
         for ci, ((a, b), buf) in enumerate(zip(self.chunks, self.buffers)):
@@ -118,14 +119,17 @@ class BatchedClosure:
                 works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
+        if alias and len(self.chunks) == 1:
+            n = self.S
+            return self.buffers[0][:n], self.buffers[0][n:].view(n, self.d, self.p)
         loss = torch.cat([buf[:b - a] for (a, b), buf in zip(self.chunks, self.buffers)])
         grad = torch.cat([buf[b - a:].view(b - a, self.d, self.p) for (a, b), buf in zip(self.chunks, self.buffers)])
         return loss, grad
 
-    def evaluate(self, beta, const=None, mask=None):
+    def evaluate(self, beta, const=None, mask=None, alias=False):
         """Closure of all S problems: (loss (S,), d/dbeta [or d/dXi when unconstrained], d/dconst)."""
         Xi = self.xi_from(beta, const)
-        loss, grad = self.loss_grad_xi(Xi, mask)
+        loss, grad = self.loss_grad_xi(Xi, mask, alias=alias)
         g_beta, g_const = self.grads_to(grad)
         return loss, g_beta, g_const
 

@@ -79,6 +79,190 @@ __global__ __launch_bounds__(WAVE) void lbfgs_direction_kernel(const float* __re
     }
 }
 
+
+// NaN-propagating max over the wave (torch's amax propagates NaN; fmaxf alone would drop it).
+__device__ __forceinline__ float wave_amax(float v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off, WAVE);
+        v = (v != v || o != o) ? __builtin_nanf("") : fmaxf(v, o);
+    }
+    return v;
+}
+
+// One inner iteration of torch.optim.LBFGS.step up to (and including) the parameter update, for every problem that is
+// still active -- torch/optim/lbfgs.py "compute gradient descent direction" ... "no line search, simply move with fixed
+// step" -- as ONE launch: curvature-pair update (ring buffer), two-loop recursion, step length, directional-derivative
+// test, x += t d.  act[s] goes in as "active" and comes out as "moved" (the closure has to be re-evaluated there).
+__global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ params, const float* __restrict__ g,
+                                                            const float* __restrict__ loss, unsigned char* __restrict__ act,
+                                                            long* __restrict__ n_iter, float* __restrict__ d,
+                                                            float* __restrict__ t, float* __restrict__ old_dirs,
+                                                            float* __restrict__ old_stps, float* __restrict__ ro,
+                                                            long* __restrict__ head, long* __restrict__ count,
+                                                            float* __restrict__ h_diag, float* __restrict__ prev_g,
+                                                            float* __restrict__ prev_loss, int n, int H, float lr,
+                                                            float tol_change) {
+    __shared__ float al[LB_MAXH];
+    const long s = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!act[s]) return;                                     // wave-uniform: this problem stopped earlier
+    const long ni = n_iter[s] + 1;
+    const bool first = ni == 1;
+    float* Y = old_dirs + s * (long)H * n;
+    float* Sx = old_stps + s * (long)H * n;
+    float* R = ro + s * (long)H;
+    float gv[LB_MAXC], q[LB_MAXC];
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) {
+        const int i = lane + WAVE * c;
+        gv[c] = i < n ? g[s * n + i] : 0.0f;
+    }
+    int m = first ? 0 : (int)count[s], h0 = first ? 0 : (int)head[s];
+    float hd = first ? 1.0f : h_diag[s];
+    if (!first) {                                            // "do lbfgs update (update memory)"
+        const float told = t[s];
+        float y[LB_MAXC], sv[LB_MAXC], p_ys = 0.0f, p_yy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int i = lane + WAVE * c;
+            y[c] = i < n ? gv[c] - prev_g[s * n + i] : 0.0f;
+            sv[c] = i < n ? d[s * n + i] * told : 0.0f;
+            p_ys = fmaf(y[c], sv[c], p_ys);
+            p_yy = fmaf(y[c], y[c], p_yy);
+        }
+        const float ys = wave_sum(p_ys);
+        if (ys > 1e-10f) {
+            const bool full = m == H;
+            const int pos = full ? h0 : (h0 + m) % H;        // overwrite the oldest pair when the memory is full
+#pragma unroll
+            for (int c = 0; c < LB_MAXC; ++c) {
+                const int i = lane + WAVE * c;
+                if (i < n) {
+                    Y[pos * n + i] = y[c];
+                    Sx[pos * n + i] = sv[c];
+                }
+            }
+            if (lane == 0) R[pos] = 1.0f / ys;
+            if (full) h0 = (h0 + 1) % H; else m += 1;
+            hd = ys / wave_sum(p_yy);
+        }
+    }
+    // two-loop recursion over the m stored pairs (this wave's own writes above are visible to it: same lanes, same
+    // addresses for Y / Sx; R[pos] was written by lane 0 and is re-read below through the same lane + a broadcast)
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) q[c] = -gv[c];
+    for (int k = m - 1; k >= 0; --k) {
+        const int slot = (h0 + k) % H;
+        float part = 0.0f;
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int i = lane + WAVE * c;
+            if (i < n) part = fmaf(Sx[slot * n + i], q[c], part);
+        }
+        const float rk = __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
+        const float a = wave_sum(part) * rk;
+        if (lane == 0) al[k] = a;
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int i = lane + WAVE * c;
+            if (i < n) q[c] = fmaf(-a, Y[slot * n + i], q[c]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) q[c] *= hd;
+    for (int k = 0; k < m; ++k) {
+        const int slot = (h0 + k) % H;
+        float part = 0.0f;
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int i = lane + WAVE * c;
+            if (i < n) part = fmaf(Y[slot * n + i], q[c], part);
+        }
+        const float rk = __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
+        const float coef = al[k] - wave_sum(part) * rk;
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int i = lane + WAVE * c;
+            if (i < n) q[c] = fmaf(coef, Sx[slot * n + i], q[c]);
+        }
+    }
+    // step length, directional derivative, move
+    float p_abs = 0.0f, p_gtd = 0.0f;
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) {
+        p_abs += fabsf(gv[c]);
+        p_gtd = fmaf(gv[c], q[c], p_gtd);
+    }
+    const float tn = first ? fminf(1.0f, 1.0f / wave_sum(p_abs)) * lr : lr;
+    const float gtd = wave_sum(p_gtd);
+    const bool live = !(gtd > -tol_change);
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) {
+        const int i = lane + WAVE * c;
+        if (i < n) {
+            d[s * n + i] = q[c];
+            prev_g[s * n + i] = gv[c];
+            if (live) params[s * n + i] = __fadd_rn(params[s * n + i], __fmul_rn(tn, q[c]));
+        }
+    }
+    if (lane == 0) {
+        n_iter[s] = ni;
+        head[s] = h0;
+        count[s] = m;
+        h_diag[s] = hd;
+        t[s] = tn;
+        prev_loss[s] = loss[s];
+        act[s] = live ? 1 : 0;
+    }
+}
+
+// The part of the iteration after the closure has been re-evaluated: problems that moved take the new loss / gradient
+// and run torch's three stopping tests (optimality, step size, loss change); act[s]: "moved" in, "still active" out.
+//
+// ``params`` != nullptr: the closure handed over the bare data term; the objective is  w_x * loss + w_reg * |params|_1
+// (train.py:680-688: L1 over the raw parameters) and its gradient  w_x * g + w_reg * sign(params)  -- added here, in
+// the arithmetic of the tensor-op form (products rounded, then one add), instead of seven more launches.
+__global__ __launch_bounds__(WAVE) void lbfgs_accept_kernel(const float* __restrict__ new_loss, const float* __restrict__ new_g,
+                                                            float* __restrict__ loss, float* __restrict__ g,
+                                                            unsigned char* __restrict__ act, const float* __restrict__ d,
+                                                            const float* __restrict__ t, const float* __restrict__ prev_loss,
+                                                            int n, float tol_grad, float tol_change,
+                                                            const float* __restrict__ params, float w_x, float w_reg) {
+    const long s = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!act[s]) return;
+    const float tt = t[s];
+    float nl = new_loss[s];
+    float gmax = 0.0f, dmax = 0.0f, p_l1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) {
+        const int i = lane + WAVE * c;
+        if (i < n) {
+            float v = new_g[s * n + i];
+            if (params != nullptr) {
+                const float pv = params[s * n + i];
+                const float sg = (float)(pv > 0.0f) - (float)(pv < 0.0f);      // torch.sign: 0 at 0 and at NaN
+                v = __fadd_rn(__fmul_rn(w_x, v), __fmul_rn(w_reg, sg));
+                p_l1 += fabsf(pv);
+            }
+            g[s * n + i] = v;
+            const float av = fabsf(v), ad = fabsf(d[s * n + i] * tt);
+            gmax = (av != av || gmax != gmax) ? __builtin_nanf("") : fmaxf(gmax, av);
+            dmax = (ad != ad || dmax != dmax) ? __builtin_nanf("") : fmaxf(dmax, ad);
+        }
+    }
+    gmax = wave_amax(gmax);
+    dmax = wave_amax(dmax);
+    if (params != nullptr) nl = __fadd_rn(__fmul_rn(w_x, nl), __fmul_rn(w_reg, wave_sum(p_l1)));
+    if (lane == 0) {
+        loss[s] = nl;
+        const bool stop = (gmax <= tol_grad) || (dmax <= tol_change) || (fabsf(nl - prev_loss[s]) < tol_change);
+        act[s] = stop ? 0 : 1;
+    }
+}
+
 }  // namespace symode
 
 extern "C" int symode_lbfgs_direction(const float* g, const float* old_dirs, const float* old_stps, const float* ro,
@@ -89,6 +273,35 @@ extern "C" int symode_lbfgs_direction(const float* g, const float* old_dirs, con
     if (!g || !old_dirs || !old_stps || !ro || !head || !count || !h_diag || !d_out) return SYMODE_E_NULLPTR;
     lbfgs_direction_kernel<<<dim3((unsigned)n_problems), dim3(WAVE), 0, (hipStream_t)stream>>>(
         g, old_dirs, old_stps, ro, head, count, h_diag, n, history, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SYMODE_OK : (int)e;
+}
+
+extern "C" int symode_lbfgs_update(float* params, const float* g, const float* loss, unsigned char* act, long* n_iter, float* d,
+                                   float* t, float* old_dirs, float* old_stps, float* ro, long* head, long* count,
+                                   float* h_diag, float* prev_g, float* prev_loss, long n_problems, int n, int history,
+                                   float lr, float tol_change, void* stream) {
+    using namespace symode;
+    if (n_problems < 1 || n < 1 || n > WAVE * LB_MAXC || history < 1 || history > LB_MAXH) return SYMODE_E_BADSIZE;
+    if (!params || !g || !loss || !act || !n_iter || !d || !t || !old_dirs || !old_stps || !ro || !head || !count || !h_diag ||
+        !prev_g || !prev_loss)
+        return SYMODE_E_NULLPTR;
+    lbfgs_update_kernel<<<dim3((unsigned)n_problems), dim3(WAVE), 0, (hipStream_t)stream>>>(
+        params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history, lr,
+        tol_change);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SYMODE_OK : (int)e;
+}
+
+extern "C" int symode_lbfgs_accept(const float* new_loss, const float* new_g, float* loss, float* g, unsigned char* act,
+                                   const float* d, const float* t, const float* prev_loss, long n_problems, int n,
+                                   float tol_grad, float tol_change, const float* params, float w_x, float w_reg,
+                                   void* stream) {
+    using namespace symode;
+    if (n_problems < 1 || n < 1 || n > WAVE * LB_MAXC) return SYMODE_E_BADSIZE;
+    if (!new_loss || !new_g || !loss || !g || !act || !d || !t || !prev_loss) return SYMODE_E_NULLPTR;
+    lbfgs_accept_kernel<<<dim3((unsigned)n_problems), dim3(WAVE), 0, (hipStream_t)stream>>>(
+        new_loss, new_g, loss, g, act, d, t, prev_loss, n, tol_grad, tol_change, params, w_x, w_reg);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SYMODE_OK : (int)e;
 }

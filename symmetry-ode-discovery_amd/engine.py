@@ -62,6 +62,8 @@ _SIGNATURES = {
                                      c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_lbfgs_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                        c_int, c_void_p, c_void_p]),
+    "symode_lbfgs_update": (c_int, [c_void_p] * 15 + [c_long, c_int, c_int, c_float, c_float, c_void_p]),
+    "symode_lbfgs_accept": (c_int, [c_void_p] * 8 + [c_long, c_int, c_float, c_float, c_void_p, c_float, c_float, c_void_p]),
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
 
@@ -529,6 +531,44 @@ class HipEngine:
                                                     self._ptr(self._dev(h_diag, "h_diag")), S, n, H, self._ptr(out),
                                                     self._stream(g)), "symode_lbfgs_direction")
         return out
+
+    def lbfgs_update(self, params, g, loss, act, st, lr, tol_change):
+        """In place: one L-BFGS inner iteration up to the move x += t d for every active problem (``st``: the
+        optimiser's state tensors, see sweep.BatchedLBFGS); ``act`` (S,) bool: active in, moved out."""
+        S, n = params.shape
+        H = st.old_dirs.shape[1]
+        for name, ten, dt in (("params", params, torch.float32), ("g", g, torch.float32), ("loss", loss, torch.float32),
+                              ("act", act, torch.bool), ("n_iter", st.n_iter, torch.int64), ("d", st.d, torch.float32),
+                              ("t", st.t, torch.float32), ("old_dirs", st.old_dirs, torch.float32),
+                              ("old_stps", st.old_stps, torch.float32), ("ro", st.ro, torch.float32),
+                              ("head", st.head, torch.int64), ("hist", st.hist, torch.int64),
+                              ("H_diag", st.H_diag, torch.float32), ("prev_g", st.prev_g, torch.float32),
+                              ("prev_loss", st.prev_loss, torch.float32)):
+            if not (ten.is_cuda and ten.dtype == dt and ten.is_contiguous()):
+                raise SymodeError(f"lbfgs_update: {name} must be a contiguous {dt} GPU tensor (updated in place)")
+        self._check(self.lib.symode_lbfgs_update(self._ptr(params), self._ptr(g), self._ptr(loss), self._ptr(act),
+                                                 self._ptr(st.n_iter), self._ptr(st.d), self._ptr(st.t), self._ptr(st.old_dirs),
+                                                 self._ptr(st.old_stps), self._ptr(st.ro), self._ptr(st.head), self._ptr(st.hist),
+                                                 self._ptr(st.H_diag), self._ptr(st.prev_g), self._ptr(st.prev_loss), S, n, H,
+                                                 float(lr), float(tol_change), self._stream(params)), "symode_lbfgs_update")
+
+    def lbfgs_accept(self, new_loss, new_g, loss, g, act, st, tol_grad, tol_change, l1=None):
+        """In place: moved problems take the re-evaluated loss / gradient and run the stopping tests; ``act``: moved in,
+        still active out.  ``l1 = (params, w_x, w_reg)``: new_loss / new_g are the bare data term, the kernel forms
+        w_x * loss + w_reg * |params|_1 and its gradient."""
+        S, n = g.shape
+        params, w_x, w_reg = (None, 1.0, 0.0) if l1 is None else l1
+        if params is not None and not (params.is_cuda and params.dtype == torch.float32 and params.is_contiguous()
+                                       and params.shape == g.shape):
+            raise SymodeError("lbfgs_accept: params must be a contiguous fp32 GPU tensor shaped like g")
+        new_loss, new_g = self._dev(new_loss, "new_loss"), self._dev(new_g, "new_g")
+        for name, ten, dt in (("loss", loss, torch.float32), ("g", g, torch.float32), ("act", act, torch.bool)):
+            if not (ten.is_cuda and ten.dtype == dt and ten.is_contiguous()):
+                raise SymodeError(f"lbfgs_accept: {name} must be a contiguous {dt} GPU tensor (updated in place)")
+        self._check(self.lib.symode_lbfgs_accept(self._ptr(new_loss), self._ptr(new_g), self._ptr(loss), self._ptr(g),
+                                                 self._ptr(act), self._ptr(st.d), self._ptr(st.t), self._ptr(st.prev_loss), S, n,
+                                                 float(tol_grad), float(tol_change), self._ptr(params), float(w_x),
+                                                 float(w_reg), self._stream(g)), "symode_lbfgs_accept")
 
 
 _ENGINE = None

@@ -99,9 +99,12 @@ class BatchedLBFGS:
     stopping tests of torch/optim/lbfgs.py (defaults: max_iter 20, tolerance_grad 1e-7, tolerance_change
     1e-9, history 100).  Problems that stop early simply stop changing.
 
-    Everything is mask arithmetic -- no host synchronisation inside ``step`` -- and the two-loop recursion
-    over the curvature pairs (ring buffers with per-problem head / count) is ONE kernel, a wavefront per
-    problem (symode_lbfgs_direction), when the variables live on the GPU.
+    Everything is mask arithmetic -- no host synchronisation inside ``step``.  With the variables on the GPU the
+    optimiser side of an inner iteration is TWO kernels, a wavefront per problem: symode_lbfgs_update (curvature
+    memory in ring buffers with per-problem head / count, two-loop recursion, step length, move) and
+    symode_lbfgs_accept (take the re-evaluated loss / gradient, stopping tests); the tensor-op form below is the
+    same arithmetic statement by statement (CPU / gloo runs, ``SYMODE_LBFGS_FUSED=0``) with only the two-loop
+    recursion as a kernel (symode_lbfgs_direction).
     """
 
     def __init__(self, params, lr, max_iter=20, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, engine=None,
@@ -128,6 +131,10 @@ class BatchedLBFGS:
         self._act = torch.zeros(S, dtype=torch.bool, device=dev)
         # HIP-graph replay of the inner iteration: GPU variables + the direction kernel (no host sync inside) only
         self.use_graph = bool(use_graph and params.is_cuda and self.engine is not None)
+        # the whole optimiser side of an iteration as two kernels (symode_lbfgs_update / _accept), a wave per problem
+        self.data_term = None          # (closure of the bare data term, w_x, w_reg): objective = w_x * data + w_reg * |P|_1
+        self.fused = bool(self.engine is not None and hasattr(self.engine, 'lbfgs_update') and dt == torch.float32
+                          and params.is_contiguous() and os.environ.get('SYMODE_LBFGS_FUSED', '1') != '0')
         self._graph, self._graph_closure, self._warm = None, None, 0
 
     def reset(self, which):
@@ -163,6 +170,16 @@ class BatchedLBFGS:
         """One inner iteration of every problem on the persistent buffers (self.P, _loss, _g, _act and the optimiser
         state): everything is updated in place, so the sequence of launches can be captured once and replayed."""
         P, g, loss, act = self.P, self._g, self._loss, self._act
+        if self.fused:                                         # two launches around the closure instead of ~60
+            self.engine.lbfgs_update(P, g, loss, act, self, self.lr, self.tol_c)
+            if evaluate and self.data_term is not None:        # bare data term; scale + L1 term added by the accept kernel
+                raw, w_x, w_reg = self.data_term
+                nl, ng = raw(P)
+                self.engine.lbfgs_accept(nl, ng, loss, g, act, self, self.tol_g, self.tol_c, l1=(P, w_x, w_reg))
+            elif evaluate:
+                nl, ng = closure(P)
+                self.engine.lbfgs_accept(nl, ng, loss, g, act, self, self.tol_g, self.tol_c)
+            return
         self.n_iter.add_(act.long())
         first = act & (self.n_iter == 1)
         upd = act & ~first
@@ -267,15 +284,22 @@ class SeedSweepLBFGS:
         r = c.Q.shape[1]
         return P[:, :r], P[:, r:].reshape(c.S, c.d, 1)
 
-    def _closure(self, P):
+    def _data_term(self, P, alias=True):
+        """loss, gradient of the bare MSE (+ regulariser the closure carries) w.r.t. the flat parameters.  ``alias``:
+        the results may be views of the closure's output buffer (they are consumed before the next evaluation)."""
         c = self.c
         a, b = self._split(P)
-        loss, ga, gb = c.evaluate(a.contiguous(), b, mask=self.mask)
+        loss, ga, gb = c.evaluate(a.contiguous(), b, mask=self.mask, **({'alias': True} if alias and self._can_alias else {}))
         if gb is None and c.Q is not None:                                  # constrain_constant: const is a parameter the
             gb = torch.zeros(c.S, c.d, 1, device=P.device, dtype=P.dtype)   # model does not read (sindy.py:60, 173-175)
         g = ga.reshape(c.S, -1) if gb is None else torch.cat([ga, gb.reshape(c.S, -1)], dim=1)
-        loss, g = self.w_x * loss, self.w_x * g
-        if self.reg_type == "l1":                                           # over the raw parameters (train.py:681)
+        return loss, g
+
+    def _closure(self, P):
+        loss, g = self._data_term(P, alias=False)
+        if self.w_x != 1.0:
+            loss, g = self.w_x * loss, self.w_x * g
+        if self.reg_type == "l1" and self.w_reg != 0.0:                     # over the raw parameters (train.py:681)
             loss = loss + self.w_reg * P.abs().sum(1)
             g = g + self.w_reg * torch.sign(P)
         return loss, g
@@ -303,6 +327,9 @@ class SeedSweepLBFGS:
         graph_ok = P.is_cuda and not getattr(c, 'distributed', False) and os.environ.get('SYMODE_SWEEP_GRAPH', '1') != '0'
         opt = BatchedLBFGS(P, self.lr, engine=getattr(c, 'engine', None) if P.is_cuda else None, use_graph=graph_ok)
         closure = self._closure                               # ONE bound-method object: the captured graph is tied to it
+        self._can_alias = 'alias' in getattr(getattr(c.evaluate, '__code__', None), 'co_varnames', ())
+        if opt.fused:
+            opt.data_term = (self._data_term, self.w_x, self.w_reg if self.reg_type == "l1" else 0.0)
         prev, pprev = P.clone(), P.clone()
         n_iters = torch.zeros(S, dtype=torch.long, device=P.device)
         done = torch.zeros(S, dtype=torch.bool, device=P.device)
