@@ -203,6 +203,10 @@ int symode_lbfgs_direction(const float* g, const float* old_dirs, const float* o
                            const long* head, const long* count, const float* h_diag, long n_problems, int n,
                            int history, float* d_out, void* stream);
 
+/* Self-test hook: every lane's wave-wide sum of in (n_waves * 64 floats) by the shuffle butterfly and by the
+ * permlane-swap / DPP form the L-BFGS kernels use; the two must agree bit for bit (tests/test_gpu_kernels.py). */
+int symode_selftest_wave_sum(const float* in, float* butterfly_out, float* dpp_out, long n_waves, void* stream);
+
 /* One inner iteration of torch.optim.LBFGS.step (no line search) for n_problems problems, up to and including the move
  * x += t d: curvature-pair update of the ring buffers, two-loop recursion, step length (first iteration:
  * min(1, 1/|g|_1) lr), directional-derivative test.  One wavefront per problem, one launch for everything

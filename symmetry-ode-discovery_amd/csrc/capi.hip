@@ -34,9 +34,9 @@ inline int gram_grid(long n, long S) {
         const long v = e ? atol(e) : 1024;
         return v < 2 ? 2 : v;
     }();
-    const int g = grid_x_for(n, S, 1);
+    const long g = grid_x_by_points(n, 1);
     const long cap = S >= total / 2 ? 2 : total / S;
-    return g > cap ? (int)cap : g;
+    return (int)(g > cap ? cap : g);
 }
 
 inline int small_grid_cap() {
@@ -81,7 +81,9 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
     const int T = (F + 15) / 16;
     const size_t gram_partial = (size_t)(T * (T + 1) / 2) * 256;
     const size_t nacc = 2 + (size_t)ops->d * ops->p;          // widest row: the fused closure keeps two scalar sums
-    const size_t g_red = (size_t)grid_x_for(n, S, 1);   // widest grid any reduction uses
+    size_t g_red = (size_t)grid_x_for(n, S, 1);         // widest grid any reduction uses
+    if ((size_t)gram_grid(n, S) > g_red) g_red = (size_t)gram_grid(n, S);
+    if ((size_t)gram_valu_grid(n, S, ops->d) > g_red) g_red = (size_t)gram_valu_grid(n, S, ops->d);
     const size_t a = (size_t)S * g_red * nacc;
     const size_t b = (size_t)S * g_red * gram_partial;
     return (size_t)WS_HEADER_DOUBLES + (a > b ? a : b);      // [magic + tickets | partial rows]

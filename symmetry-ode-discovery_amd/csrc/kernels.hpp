@@ -16,15 +16,25 @@ constexpr int BLOCK = 256;
 #define SYMODE_MAP_CHUNKS 1
 #endif
 constexpr int MAP_CHUNKS_PER_THREAD = SYMODE_MAP_CHUNKS;   // chunks a thread of a map kernel visits (grid = index space / this)
-// total workgroups of a batched launch are capped near this (256 CUs x 8 resident workgroups x 4);
-// SYMODE_MAX_GRID overrides it for tuning runs
-inline int max_grid_x() {
-    static const int v = [] {
-        const char* e = getenv("SYMODE_MAX_GRID");
-        const int g = e ? atoi(e) : 8192;
-        return g < 256 ? 256 : g;
-    }();
-    return v;
+// Workgroup budget of a BATCHED reduction launch (S > 1 problems on grid.y).  Every workgroup pays a fixed epilogue (LDS
+// transpose of its d*p + 1 sums, a partial row, a ticket) and the last one of each problem adds that problem's rows
+// alone, so what a launch wants is few, long-lived workgroups: ~16 K points each, between one per CU and four per CU in
+// all.  Measured on loss_grad, order 3 (us at a budget of 256 / 1024 / 8192 workgroups; round 2 shipped 8192):
+//   16 x 125 000: 11.9 / 18.1 / 55.3     64 x 50 000: 11.4 / 13.4 / 64.9     256 x 50 000: 32.4 / 35.0 / 70.1
+//   512 x 125 000 and up: the floor of two workgroups per problem decides (162-178 us either way).
+// SYMODE_MAX_GRID fixes the budget for tuning runs; SYMODE_MIN_GRID_X the floor per problem.
+inline long batch_grid_budget(long total_points) {
+    static const long fixed = getenv("SYMODE_MAX_GRID") ? atol(getenv("SYMODE_MAX_GRID")) : 0;
+    if (fixed > 0) return fixed < 2 ? 2 : fixed;
+    long b = total_points / 16384;
+    if (b < 256) b = 256;
+    if (b > 1024) b = 1024;
+    return b;
+}
+
+inline long min_grid_x() {
+    static const long v = getenv("SYMODE_MIN_GRID_X") ? atol(getenv("SYMODE_MIN_GRID_X")) : 2;
+    return v < 1 ? 1 : v;
 }
 
 // One row of the dispatch table: everything the C ABI needs for one (D, ORDER, FLAGS).
@@ -71,16 +81,23 @@ struct LibOps {
 // Grid width for a streaming pass over n points (per problem), S problems on grid.y.
 // Small problems favour latency: one step per thread until every CU has two blocks; beyond that,
 // at least 4 steps per thread so the reduction epilogue amortises.
-inline int grid_x_for(long n, long S, int pts_per_thread_iter) {
+inline long grid_x_by_points(long n, int pts_per_thread_iter) {
     const long per_block = (long)BLOCK * pts_per_thread_iter;
     long g = (n + per_block - 1) / per_block;
     if (g > 512) {
         g = (n + 4 * per_block - 1) / (4 * per_block);
         if (g < 512) g = 512;
     }
-    long cap = max_grid_x() / (S < 1 ? 1 : S);
-    if (cap < 2) cap = 2;
-    if (cap > 2048) cap = 2048;        // one finalize block per problem adds the partial rows: keep them few
+    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+inline int grid_x_for(long n, long S, int pts_per_thread_iter) {
+    long g = grid_x_by_points(n, pts_per_thread_iter);
+    long cap = 2048;                   // one problem: the last workgroup adds the partial rows alone, keep them few
+    if (S > 1) {
+        cap = batch_grid_budget(n * S) / S;
+        if (cap < min_grid_x()) cap = min_grid_x();
+    }
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;

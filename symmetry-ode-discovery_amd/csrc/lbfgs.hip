@@ -94,6 +94,13 @@ __device__ __forceinline__ float wave_amax(float v) {
 // still active -- torch/optim/lbfgs.py "compute gradient descent direction" ... "no line search, simply move with fixed
 // step" -- as ONE launch: curvature-pair update (ring buffer), two-loop recursion, step length, directional-derivative
 // test, x += t d.  act[s] goes in as "active" and comes out as "moved" (the closure has to be re-evaluated there).
+//
+// STAGED: the recursion is 2m dependent steps (dot product -> axpy), and read from global memory every step pays a
+// full memory round trip (~1.5 us x 100 steps at m = 50: the launch was 10x the closure kernel it sits beside).  The
+// m pairs are therefore staged ONCE, all loads in flight together, into LDS in logical order ([k][i], k = 0 oldest) --
+// the pair made in this launch straight from registers -- and the loops run out of LDS.  Needs (2 n + 1) H floats
+// (<= 64 KB: n = 42, H = 100 is 34 KB); larger problems take the unstaged form.
+template <bool STAGED>
 __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ params, const float* __restrict__ g,
                                                             const float* __restrict__ loss, unsigned char* __restrict__ act,
                                                             long* __restrict__ n_iter, float* __restrict__ d,
@@ -104,9 +111,13 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
                                                             float* __restrict__ prev_loss, int n, int H, float lr,
                                                             float tol_change) {
     __shared__ float al[LB_MAXH];
+    extern __shared__ float staged[];                        // STAGED: Y [H][n] | S [H][n] | ro [H]
     const long s = blockIdx.x;
     const int lane = threadIdx.x;
     if (!act[s]) return;                                     // wave-uniform: this problem stopped earlier
+    float* const ldsY = staged;
+    float* const ldsS = staged + H * n;
+    float* const ldsR = staged + 2 * H * n;
     const long ni = n_iter[s] + 1;
     const bool first = ni == 1;
     float* Y = old_dirs + s * (long)H * n;
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
     }
     int m = first ? 0 : (int)count[s], h0 = first ? 0 : (int)head[s];
     float hd = first ? 1.0f : h_diag[s];
+    bool fresh = false;                                      // a pair was stored in this launch (logical slot m - 1)
     if (!first) {                                            // "do lbfgs update (update memory)"
         const float told = t[s];
         float y[LB_MAXC], sv[LB_MAXC], p_ys = 0.0f, p_yy = 0.0f;
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
             p_ys = fmaf(y[c], sv[c], p_ys);
             p_yy = fmaf(y[c], y[c], p_yy);
         }
-        const float ys = wave_sum(p_ys);
+        const float ys = wave_sum_dpp(p_ys);
         if (ys > 1e-10f) {
             const bool full = m == H;
             const int pos = full ? h0 : (h0 + m) % H;        // overwrite the oldest pair when the memory is full
@@ -145,8 +157,30 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
             }
             if (lane == 0) R[pos] = 1.0f / ys;
             if (full) h0 = (h0 + 1) % H; else m += 1;
-            hd = ys / wave_sum(p_yy);
+            hd = ys / wave_sum_dpp(p_yy);
+            fresh = true;
+            if (STAGED) {
+#pragma unroll
+                for (int c = 0; c < LB_MAXC; ++c) {
+                    const int i = lane + WAVE * c;
+                    if (i < n) {
+                        ldsY[(m - 1) * n + i] = y[c];
+                        ldsS[(m - 1) * n + i] = sv[c];
+                    }
+                }
+                if (lane == 0) ldsR[m - 1] = 1.0f / ys;
+            }
         }
+    }
+    if (STAGED) {
+        const int m_old = fresh ? m - 1 : m;                 // pairs that were in memory before this launch
+        for (int idx = lane; idx < m_old * n; idx += WAVE) {
+            const int k = idx / n, i = idx - k * n, slot = (h0 + k) % H;
+            ldsY[idx] = Y[slot * n + i];
+            ldsS[idx] = Sx[slot * n + i];
+        }
+        for (int k = lane; k < m_old; k += WAVE) ldsR[k] = R[(h0 + k) % H];
+        __syncthreads();
     }
     // two-loop recursion over the m stored pairs (this wave's own writes above are visible to it: same lanes, same
     // addresses for Y / Sx; R[pos] was written by lane 0 and is re-read below through the same lane + a broadcast)
@@ -154,19 +188,21 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
     for (int c = 0; c < LB_MAXC; ++c) q[c] = -gv[c];
     for (int k = m - 1; k >= 0; --k) {
         const int slot = (h0 + k) % H;
+        const float* srow = STAGED ? ldsS + k * n : Sx + slot * n;
+        const float* yrow = STAGED ? ldsY + k * n : Y + slot * n;
         float part = 0.0f;
 #pragma unroll
         for (int c = 0; c < LB_MAXC; ++c) {
             const int i = lane + WAVE * c;
-            if (i < n) part = fmaf(Sx[slot * n + i], q[c], part);
+            if (i < n) part = fmaf(srow[i], q[c], part);
         }
-        const float rk = __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
-        const float a = wave_sum(part) * rk;
+        const float rk = STAGED ? ldsR[k] : __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
+        const float a = wave_sum_dpp(part) * rk;
         if (lane == 0) al[k] = a;
 #pragma unroll
         for (int c = 0; c < LB_MAXC; ++c) {
             const int i = lane + WAVE * c;
-            if (i < n) q[c] = fmaf(-a, Y[slot * n + i], q[c]);
+            if (i < n) q[c] = fmaf(-a, yrow[i], q[c]);
         }
     }
     __syncthreads();
@@ -174,18 +210,20 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
     for (int c = 0; c < LB_MAXC; ++c) q[c] *= hd;
     for (int k = 0; k < m; ++k) {
         const int slot = (h0 + k) % H;
+        const float* srow = STAGED ? ldsS + k * n : Sx + slot * n;
+        const float* yrow = STAGED ? ldsY + k * n : Y + slot * n;
         float part = 0.0f;
 #pragma unroll
         for (int c = 0; c < LB_MAXC; ++c) {
             const int i = lane + WAVE * c;
-            if (i < n) part = fmaf(Y[slot * n + i], q[c], part);
+            if (i < n) part = fmaf(yrow[i], q[c], part);
         }
-        const float rk = __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
-        const float coef = al[k] - wave_sum(part) * rk;
+        const float rk = STAGED ? ldsR[k] : __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
+        const float coef = al[k] - wave_sum_dpp(part) * rk;
 #pragma unroll
         for (int c = 0; c < LB_MAXC; ++c) {
             const int i = lane + WAVE * c;
-            if (i < n) q[c] = fmaf(coef, Sx[slot * n + i], q[c]);
+            if (i < n) q[c] = fmaf(coef, srow[i], q[c]);
         }
     }
     // step length, directional derivative, move
@@ -195,8 +233,8 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
         p_abs += fabsf(gv[c]);
         p_gtd = fmaf(gv[c], q[c], p_gtd);
     }
-    const float tn = first ? fminf(1.0f, 1.0f / wave_sum(p_abs)) * lr : lr;
-    const float gtd = wave_sum(p_gtd);
+    const float tn = first ? fminf(1.0f, 1.0f / wave_sum_dpp(p_abs)) * lr : lr;
+    const float gtd = wave_sum_dpp(p_gtd);
     const bool live = !(gtd > -tol_change);
 #pragma unroll
     for (int c = 0; c < LB_MAXC; ++c) {
@@ -277,6 +315,25 @@ extern "C" int symode_lbfgs_direction(const float* g, const float* old_dirs, con
     return e == hipSuccess ? SYMODE_OK : (int)e;
 }
 
+namespace symode {
+__global__ __launch_bounds__(WAVE) void wave_sum_selftest_kernel(const float* __restrict__ in, float* __restrict__ butterfly,
+                                                                 float* __restrict__ dpp) {
+    const long i = (long)blockIdx.x * WAVE + threadIdx.x;
+    const float v = in[i];
+    butterfly[i] = wave_sum(v);
+    dpp[i] = wave_sum_dpp(v);
+}
+}  // namespace symode
+
+extern "C" int symode_selftest_wave_sum(const float* in, float* butterfly_out, float* dpp_out, long n_waves, void* stream) {
+    using namespace symode;
+    if (n_waves < 1) return SYMODE_E_BADSIZE;
+    if (!in || !butterfly_out || !dpp_out) return SYMODE_E_NULLPTR;
+    wave_sum_selftest_kernel<<<dim3((unsigned)n_waves), dim3(WAVE), 0, (hipStream_t)stream>>>(in, butterfly_out, dpp_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SYMODE_OK : (int)e;
+}
+
 extern "C" int symode_lbfgs_update(float* params, const float* g, const float* loss, unsigned char* act, long* n_iter, float* d,
                                    float* t, float* old_dirs, float* old_stps, float* ro, long* head, long* count,
                                    float* h_diag, float* prev_g, float* prev_loss, long n_problems, int n, int history,
@@ -286,9 +343,15 @@ extern "C" int symode_lbfgs_update(float* params, const float* g, const float* l
     if (!params || !g || !loss || !act || !n_iter || !d || !t || !old_dirs || !old_stps || !ro || !head || !count || !h_diag ||
         !prev_g || !prev_loss)
         return SYMODE_E_NULLPTR;
-    lbfgs_update_kernel<<<dim3((unsigned)n_problems), dim3(WAVE), 0, (hipStream_t)stream>>>(
-        params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history, lr,
-        tol_change);
+    const size_t stage_bytes = ((size_t)2 * n + 1) * history * sizeof(float);
+    if (stage_bytes <= 60 * 1024)
+        lbfgs_update_kernel<true><<<dim3((unsigned)n_problems), dim3(WAVE), stage_bytes, (hipStream_t)stream>>>(
+            params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history, lr,
+            tol_change);
+    else
+        lbfgs_update_kernel<false><<<dim3((unsigned)n_problems), dim3(WAVE), 0, (hipStream_t)stream>>>(
+            params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history, lr,
+            tol_change);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SYMODE_OK : (int)e;
 }

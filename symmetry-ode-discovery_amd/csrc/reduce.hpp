@@ -13,6 +13,32 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The same total, BIT-IDENTICAL to the butterfly above (same partners, same order: lane ^ 32, 16, 8, 4, 2, 1; fp addition
+// commutes, so both partners of a step hold the same bits), without its six ds_bpermute round trips -- for the serial
+// dot products of the L-BFGS recursion (lbfgs.hip), where the reduction IS the critical path:
+//   lane ^ 32, lane ^ 16   gfx950's v_permlane32_swap / v_permlane16_swap with both operands = v: the two results are
+//                          (lower half, lower half) / (upper half, upper half) resp. (even rows, odd rows), their sum is
+//                          the butterfly step;
+//   lane ^ 8               DPP row_ror:8;
+//   lane ^ 4               DPP row_shl:4 into the quads with bit 2 clear, row_shr:4 into the others (bank masks);
+//   lane ^ 2, lane ^ 1     DPP quad permutes.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, false));
+}
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    v += dpp_take<0x128, 0xf>(v, v);                                  // row_ror:8
+    v += dpp_take<0x114, 0xa>(dpp_take<0x104, 0x5>(v, v), v);         // row_shl:4 -> quads 0, 2; row_shr:4 -> quads 1, 3
+    v += dpp_take<0x4E, 0xf>(v, v);                                   // quad_perm:[2,3,0,1]
+    v += dpp_take<0xB1, 0xf>(v, v);                                   // quad_perm:[1,0,3,2]
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);

@@ -62,6 +62,7 @@ _SIGNATURES = {
                                      c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_lbfgs_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                        c_int, c_void_p, c_void_p]),
+    "symode_selftest_wave_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "symode_lbfgs_update": (c_int, [c_void_p] * 15 + [c_long, c_int, c_int, c_float, c_float, c_void_p]),
     "symode_lbfgs_accept": (c_int, [c_void_p] * 8 + [c_long, c_int, c_float, c_float, c_void_p, c_float, c_float, c_void_p]),
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),

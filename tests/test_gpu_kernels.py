@@ -685,3 +685,22 @@ def test_ticket_handoff_under_uneven_load_every_word(eng):
                 bad += (outs[k][0] != want[k][0]).sum() + (outs[k][1] != want[k][1]).sum()
         torch.cuda.synchronize()
         assert int(bad.item()) == 0, (S, n, order, int(bad.item()))
+
+
+def test_dpp_wave_sum_is_bit_identical_to_the_shuffle_butterfly(eng):
+    """reduce.hpp::wave_sum_dpp (v_permlane32/16_swap + DPP row / quad permutes; the L-BFGS kernels' dot products) pairs the
+    same lanes in the same order as the __shfl_xor butterfly: every lane of every wave must hold the same bits, on
+    random data, data spanning 30 binades (where association order shows) and a one-hot pattern per lane (routing)."""
+    import ctypes
+    torch.manual_seed(0)
+    onehot = torch.eye(64, device="cuda").reshape(-1) * torch.arange(1, 65, device="cuda").repeat_interleave(64).float()
+    wide = torch.randn(64 * 300, device="cuda") * torch.exp2(torch.randint(-15, 15, (64 * 300,), device="cuda").float())
+    for data in (torch.randn(64 * 500, device="cuda"), wide, onehot):
+        a, b = torch.empty_like(data), torch.empty_like(data)
+        rc = eng.lib.symode_selftest_wave_sum(ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(a.data_ptr()),
+                                              ctypes.c_void_p(b.data_ptr()), data.numel() // 64,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert torch.allclose(a.view(-1, 64)[:, 0], data.view(-1, 64).double().sum(1).float(), rtol=1e-4, atol=1e-4 * data.abs().max().item())
