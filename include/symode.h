@@ -219,6 +219,15 @@ int symode_lbfgs_update(float* params, const float* g, const float* loss, unsign
                         float* prev_g, float* prev_loss, long n_problems, int n, int history, float lr,
                         float tol_change, void* stream);
 
+/* symode_lbfgs_accept (below) followed by symode_lbfgs_update as ONE launch: problems that moved take new_loss / new_g
+ * (l1 != 0: as the bare data term, objective w_x * data + w_reg * |params|_1), run the stopping tests, and those still
+ * active go straight into the next iteration's update.  Between two closure evaluations the optimiser is one kernel. */
+int symode_lbfgs_accept_update(const float* new_loss, const float* new_g, float tol_grad, int l1, float w_x, float w_reg,
+                               float* params, float* g, float* loss, unsigned char* act, long* n_iter, float* d, float* t,
+                               float* old_dirs, float* old_stps, float* ro, long* head, long* count, float* h_diag,
+                               float* prev_g, float* prev_loss, long n_problems, int n, int history, float lr,
+                               float tol_change, void* stream);
+
 /* Second half of that iteration, after the closure was re-evaluated at the moved parameters: problems with act != 0
  * take new_loss / new_g into loss / g and run the three stopping tests of torch/optim/lbfgs.py (max|g| <= tol_grad,
  * max|t d| <= tol_change, |loss - prev_loss| < tol_change); act: in = moved, out = still active.

@@ -99,41 +99,97 @@ __device__ __forceinline__ float wave_amax(float v) {
 // full memory round trip (~1.5 us x 100 steps at m = 50: the launch was 10x the closure kernel it sits beside).  The
 // m pairs are therefore staged ONCE, all loads in flight together, into LDS in logical order ([k][i], k = 0 oldest) --
 // the pair made in this launch straight from registers -- and the loops run out of LDS.  Needs (2 n + 1) H floats
-// (<= 64 KB: n = 42, H = 100 is 34 KB); larger problems take the unstaged form.
-template <bool STAGED>
-__global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ params, const float* __restrict__ g,
-                                                            const float* __restrict__ loss, unsigned char* __restrict__ act,
+// (<= 60 KB: n = 42, H = 100 is 34 KB); larger problems take the unstaged form (NC = 0).
+//
+// The staged loops (NC = ceil(n / 64) components per lane, compile time) are written for the dependent chain: the rows
+// of the NEXT pair are fetched from LDS while the current dot product reduces (wave_sum_dpp), lanes beyond n are
+// zeroed by selects at fetch time instead of branches around every use, and the m alphas stay in two registers (lane k
+// keeps alpha_k, read back with v_readlane) instead of going through LDS.
+//
+// ACCEPT: the launch first finishes the PREVIOUS iteration (what lbfgs_accept_kernel does: take the re-evaluated loss /
+// gradient, stopping tests) and carries on into this one if the problem is still active -- between two closure
+// evaluations the optimiser is then ONE launch, and the accepted gradient never leaves the registers.
+struct AcceptArgs {
+    const float* new_loss;   // (S)     closure value at the moved parameters
+    const float* new_g;      // (S, n)  its gradient
+    float tol_grad;
+    int l1;                  // != 0: new_loss / new_g are the bare data term, objective = w_x * data + w_reg * |params|_1
+    float w_x, w_reg;
+};
+
+template <int NC, bool ACCEPT>
+__global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ params, float* __restrict__ g,
+                                                            float* __restrict__ loss, unsigned char* __restrict__ act,
                                                             long* __restrict__ n_iter, float* __restrict__ d,
                                                             float* __restrict__ t, float* __restrict__ old_dirs,
                                                             float* __restrict__ old_stps, float* __restrict__ ro,
                                                             long* __restrict__ head, long* __restrict__ count,
                                                             float* __restrict__ h_diag, float* __restrict__ prev_g,
                                                             float* __restrict__ prev_loss, int n, int H, float lr,
-                                                            float tol_change) {
+                                                            float tol_change, AcceptArgs acc) {
+    constexpr bool STAGED = NC > 0;
     __shared__ float al[LB_MAXH];
-    extern __shared__ float staged[];                        // STAGED: Y [H][n] | S [H][n] | ro [H]
+    extern __shared__ float staged[];                        // STAGED: Y [H][n] | S [H][n] | ro [H] | 256 floats of padding
     const long s = blockIdx.x;
     const int lane = threadIdx.x;
-    if (!act[s]) return;                                     // wave-uniform: this problem stopped earlier
+    if (!__builtin_amdgcn_readfirstlane((int)act[s])) return;   // wave-uniform: this problem stopped earlier
     float* const ldsY = staged;
     float* const ldsS = staged + H * n;
     float* const ldsR = staged + 2 * H * n;
-    const long ni = n_iter[s] + 1;
+    float gv[LB_MAXC], q[LB_MAXC];
+    float loss_s;
+    if constexpr (ACCEPT) {
+        const float tt = t[s];
+        float nl = acc.new_loss[s];
+        float gmax = 0.0f, dmax = 0.0f, p_l1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int i = lane + WAVE * c;
+            gv[c] = 0.0f;
+            if (i < n) {
+                float v = acc.new_g[s * n + i];
+                if (acc.l1) {
+                    const float pv = params[s * n + i];
+                    const float sg = (float)(pv > 0.0f) - (float)(pv < 0.0f);
+                    v = __fadd_rn(__fmul_rn(acc.w_x, v), __fmul_rn(acc.w_reg, sg));
+                    p_l1 += fabsf(pv);
+                }
+                g[s * n + i] = v;
+                gv[c] = v;
+                const float av = fabsf(v), ad = fabsf(d[s * n + i] * tt);
+                gmax = (av != av || gmax != gmax) ? __builtin_nanf("") : fmaxf(gmax, av);
+                dmax = (ad != ad || dmax != dmax) ? __builtin_nanf("") : fmaxf(dmax, ad);
+            }
+        }
+        gmax = wave_amax(gmax);
+        dmax = wave_amax(dmax);
+        if (acc.l1) nl = __fadd_rn(__fmul_rn(acc.w_x, nl), __fmul_rn(acc.w_reg, wave_sum(p_l1)));
+        const bool stop = (gmax <= acc.tol_grad) || (dmax <= tol_change) || (fabsf(nl - prev_loss[s]) < tol_change);
+        if (lane == 0) loss[s] = nl;
+        if (__builtin_amdgcn_readfirstlane((int)stop)) {
+            if (lane == 0) act[s] = 0;
+            return;
+        }
+        loss_s = nl;
+    } else {
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int i = lane + WAVE * c;
+            gv[c] = i < n ? g[s * n + i] : 0.0f;
+        }
+        loss_s = loss[s];
+    }
+    const long ni = (long)__builtin_amdgcn_readfirstlane((int)n_iter[s]) + 1;      // (scalars: uniform loop bounds below)
     const bool first = ni == 1;
     float* Y = old_dirs + s * (long)H * n;
     float* Sx = old_stps + s * (long)H * n;
     float* R = ro + s * (long)H;
-    float gv[LB_MAXC], q[LB_MAXC];
-#pragma unroll
-    for (int c = 0; c < LB_MAXC; ++c) {
-        const int i = lane + WAVE * c;
-        gv[c] = i < n ? g[s * n + i] : 0.0f;
-    }
-    int m = first ? 0 : (int)count[s], h0 = first ? 0 : (int)head[s];
-    float hd = first ? 1.0f : h_diag[s];
+    int m = first ? 0 : __builtin_amdgcn_readfirstlane((int)count[s]);
+    int h0 = first ? 0 : __builtin_amdgcn_readfirstlane((int)head[s]);
+    float hd = first ? 1.0f : __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h_diag[s])));
     bool fresh = false;                                      // a pair was stored in this launch (logical slot m - 1)
     if (!first) {                                            // "do lbfgs update (update memory)"
-        const float told = t[s];
+        const float told = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t[s])));
         float y[LB_MAXC], sv[LB_MAXC], p_ys = 0.0f, p_yy = 0.0f;
 #pragma unroll
         for (int c = 0; c < LB_MAXC; ++c) {
@@ -143,7 +199,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
             p_ys = fmaf(y[c], sv[c], p_ys);
             p_yy = fmaf(y[c], y[c], p_yy);
         }
-        const float ys = wave_sum_dpp(p_ys);
+        const float ys = wave_sum_dpp_uniform(p_ys);
         if (ys > 1e-10f) {
             const bool full = m == H;
             const int pos = full ? h0 : (h0 + m) % H;        // overwrite the oldest pair when the memory is full
@@ -157,7 +213,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
             }
             if (lane == 0) R[pos] = 1.0f / ys;
             if (full) h0 = (h0 + 1) % H; else m += 1;
-            hd = ys / wave_sum_dpp(p_yy);
+            hd = ys / wave_sum_dpp_uniform(p_yy);
             fresh = true;
             if (STAGED) {
 #pragma unroll
@@ -174,56 +230,113 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
     }
     if (STAGED) {
         const int m_old = fresh ? m - 1 : m;                 // pairs that were in memory before this launch
-        for (int idx = lane; idx < m_old * n; idx += WAVE) {
-            const int k = idx / n, i = idx - k * n, slot = (h0 + k) % H;
-            ldsY[idx] = Y[slot * n + i];
-            ldsS[idx] = Sx[slot * n + i];
+        // the ring buffer is at most two contiguous runs of rows: slots [h0, H) then [0, ...); each is copied flat, sixteen
+        // loads in flight per lane (the 64 problems' histories sit in L2: ~0.7 us a round trip, so depth is what counts)
+        auto copy_flat = [&](const float* __restrict__ src, float* __restrict__ dst, int len) {
+#pragma unroll 16
+            for (int idx = lane; idx < len; idx += WAVE) dst[idx] = src[idx];
+        };
+        const int run0 = m_old < H - h0 ? m_old : H - h0;    // rows in the first run
+        copy_flat(Y + h0 * n, ldsY, run0 * n);
+        copy_flat(Sx + h0 * n, ldsS, run0 * n);
+        copy_flat(R + h0, ldsR, run0);
+        if (m_old > run0) {
+            copy_flat(Y, ldsY + run0 * n, (m_old - run0) * n);
+            copy_flat(Sx, ldsS + run0 * n, (m_old - run0) * n);
+            copy_flat(R, ldsR + run0, m_old - run0);
         }
-        for (int k = lane; k < m_old; k += WAVE) ldsR[k] = R[(h0 + k) % H];
         __syncthreads();
     }
-    // two-loop recursion over the m stored pairs (this wave's own writes above are visible to it: same lanes, same
-    // addresses for Y / Sx; R[pos] was written by lane 0 and is re-read below through the same lane + a broadcast)
+    // two-loop recursion over the m stored pairs
 #pragma unroll
     for (int c = 0; c < LB_MAXC; ++c) q[c] = -gv[c];
-    for (int k = m - 1; k >= 0; --k) {
-        const int slot = (h0 + k) % H;
-        const float* srow = STAGED ? ldsS + k * n : Sx + slot * n;
-        const float* yrow = STAGED ? ldsY + k * n : Y + slot * n;
-        float part = 0.0f;
+    if constexpr (STAGED) {
+        bool on[NC];
 #pragma unroll
-        for (int c = 0; c < LB_MAXC; ++c) {
-            const int i = lane + WAVE * c;
-            if (i < n) part = fmaf(srow[i], q[c], part);
+        for (int c = 0; c < NC; ++c) on[c] = lane + WAVE * c < n;
+        float sc[NC], yc[NC], sn[NC], yn[NC], rc, rn, al0 = 0.0f, al1 = 0.0f;
+        auto fetch = [&](int k, float (&sr)[NC], float (&yr)[NC], float& rr) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float sv_ = ldsS[k * n + lane + WAVE * c], yv_ = ldsY[k * n + lane + WAVE * c];
+                sr[c] = on[c] ? sv_ : 0.0f;
+                yr[c] = on[c] ? yv_ : 0.0f;
+            }
+            rr = ldsR[k];
+        };
+        if (m > 0) fetch(m - 1, sc, yc, rc);
+        for (int k = m - 1; k >= 0; --k) {                   // newest -> oldest
+            fetch(k > 0 ? k - 1 : 0, sn, yn, rn);
+            float part = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) part = fmaf(sc[c], q[c], part);
+            const float a = wave_sum_dpp_uniform(part) * rc;
+            al0 = lane == k ? a : al0;
+            al1 = lane == k - WAVE ? a : al1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                q[c] = fmaf(-a, yc[c], q[c]);
+                sc[c] = sn[c];
+                yc[c] = yn[c];
+            }
+            rc = rn;
         }
-        const float rk = STAGED ? ldsR[k] : __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
-        const float a = wave_sum_dpp(part) * rk;
-        if (lane == 0) al[k] = a;
 #pragma unroll
-        for (int c = 0; c < LB_MAXC; ++c) {
-            const int i = lane + WAVE * c;
-            if (i < n) q[c] = fmaf(-a, yrow[i], q[c]);
+        for (int c = 0; c < NC; ++c) q[c] *= hd;
+        if (m > 0) fetch(0, sc, yc, rc);
+        for (int k = 0; k < m; ++k) {                        // oldest -> newest
+            fetch(k + 1 < m ? k + 1 : k, sn, yn, rn);
+            float part = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) part = fmaf(yc[c], q[c], part);
+            const float alk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k < WAVE ? al0 : al1), k & (WAVE - 1)));
+            const float coef = alk - wave_sum_dpp_uniform(part) * rc;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                q[c] = fmaf(coef, sc[c], q[c]);
+                sc[c] = sn[c];
+                yc[c] = yn[c];
+            }
+            rc = rn;
         }
-    }
-    __syncthreads();
+    } else {
+        for (int k = m - 1; k >= 0; --k) {
+            const int slot = (h0 + k) % H;
+            float part = 0.0f;
 #pragma unroll
-    for (int c = 0; c < LB_MAXC; ++c) q[c] *= hd;
-    for (int k = 0; k < m; ++k) {
-        const int slot = (h0 + k) % H;
-        const float* srow = STAGED ? ldsS + k * n : Sx + slot * n;
-        const float* yrow = STAGED ? ldsY + k * n : Y + slot * n;
-        float part = 0.0f;
+            for (int c = 0; c < LB_MAXC; ++c) {
+                const int i = lane + WAVE * c;
+                if (i < n) part = fmaf(Sx[slot * n + i], q[c], part);
+            }
+            // (this wave's own writes above are visible to it: same lanes, same addresses for Y / Sx; R[pos] was written by
+            // lane 0 and is re-read through the same lane + a broadcast)
+            const float rk = __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
+            const float a = wave_sum_dpp_uniform(part) * rk;
+            if (lane == 0) al[k] = a;
 #pragma unroll
-        for (int c = 0; c < LB_MAXC; ++c) {
-            const int i = lane + WAVE * c;
-            if (i < n) part = fmaf(yrow[i], q[c], part);
+            for (int c = 0; c < LB_MAXC; ++c) {
+                const int i = lane + WAVE * c;
+                if (i < n) q[c] = fmaf(-a, Y[slot * n + i], q[c]);
+            }
         }
-        const float rk = STAGED ? ldsR[k] : __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
-        const float coef = al[k] - wave_sum_dpp(part) * rk;
+        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < LB_MAXC; ++c) {
-            const int i = lane + WAVE * c;
-            if (i < n) q[c] = fmaf(coef, srow[i], q[c]);
+        for (int c = 0; c < LB_MAXC; ++c) q[c] *= hd;
+        for (int k = 0; k < m; ++k) {
+            const int slot = (h0 + k) % H;
+            float part = 0.0f;
+#pragma unroll
+            for (int c = 0; c < LB_MAXC; ++c) {
+                const int i = lane + WAVE * c;
+                if (i < n) part = fmaf(Y[slot * n + i], q[c], part);
+            }
+            const float rk = __shfl(lane == 0 ? R[slot] : 0.0f, 0, WAVE);
+            const float coef = al[k] - wave_sum_dpp_uniform(part) * rk;
+#pragma unroll
+            for (int c = 0; c < LB_MAXC; ++c) {
+                const int i = lane + WAVE * c;
+                if (i < n) q[c] = fmaf(coef, Sx[slot * n + i], q[c]);
+            }
         }
     }
     // step length, directional derivative, move
@@ -233,8 +346,8 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
         p_abs += fabsf(gv[c]);
         p_gtd = fmaf(gv[c], q[c], p_gtd);
     }
-    const float tn = first ? fminf(1.0f, 1.0f / wave_sum_dpp(p_abs)) * lr : lr;
-    const float gtd = wave_sum_dpp(p_gtd);
+    const float tn = first ? fminf(1.0f, 1.0f / wave_sum_dpp_uniform(p_abs)) * lr : lr;
+    const float gtd = wave_sum_dpp_uniform(p_gtd);
     const bool live = !(gtd > -tol_change);
 #pragma unroll
     for (int c = 0; c < LB_MAXC; ++c) {
@@ -251,7 +364,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
         count[s] = m;
         h_diag[s] = hd;
         t[s] = tn;
-        prev_loss[s] = loss[s];
+        prev_loss[s] = loss_s;
         act[s] = live ? 1 : 0;
     }
 }
@@ -334,26 +447,58 @@ extern "C" int symode_selftest_wave_sum(const float* in, float* butterfly_out, f
     return e == hipSuccess ? SYMODE_OK : (int)e;
 }
 
+namespace symode {
+inline int launch_lbfgs_update(bool accept, float* params, float* g, float* loss, unsigned char* act, long* n_iter, float* d, float* t,
+                               float* old_dirs, float* old_stps, float* ro, long* head, long* count, float* h_diag, float* prev_g,
+                               float* prev_loss, long n_problems, int n, int history, float lr, float tol_change, AcceptArgs acc,
+                               void* stream) {
+    if (n_problems < 1 || n < 1 || n > WAVE * LB_MAXC || history < 1 || history > LB_MAXH) return SYMODE_E_BADSIZE;
+    if (!params || !g || !loss || !act || !n_iter || !d || !t || !old_dirs || !old_stps || !ro || !head || !count || !h_diag ||
+        !prev_g || !prev_loss || (accept && (!acc.new_loss || !acc.new_g)))
+        return SYMODE_E_NULLPTR;
+    const size_t stage_bytes = (((size_t)2 * n + 1) * history + 256) * sizeof(float);
+    const int nc = stage_bytes <= 60 * 1024 ? (n + WAVE - 1) / WAVE : 0;
+#define SYMODE_LBFGS_UPDATE(NC_, BYTES_)                                                                                          \
+    do {                                                                                                                          \
+        if (accept)                                                                                                               \
+            lbfgs_update_kernel<NC_, true><<<dim3((unsigned)n_problems), dim3(WAVE), BYTES_, (hipStream_t)stream>>>(              \
+                params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history,   \
+                lr, tol_change, acc);                                                                                             \
+        else                                                                                                                      \
+            lbfgs_update_kernel<NC_, false><<<dim3((unsigned)n_problems), dim3(WAVE), BYTES_, (hipStream_t)stream>>>(             \
+                params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history,   \
+                lr, tol_change, acc);                                                                                             \
+    } while (0)
+    switch (nc) {
+        case 1: SYMODE_LBFGS_UPDATE(1, stage_bytes); break;
+        case 2: SYMODE_LBFGS_UPDATE(2, stage_bytes); break;
+        case 3: SYMODE_LBFGS_UPDATE(3, stage_bytes); break;
+        case 4: SYMODE_LBFGS_UPDATE(4, stage_bytes); break;
+        default: SYMODE_LBFGS_UPDATE(0, 0); break;
+    }
+#undef SYMODE_LBFGS_UPDATE
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SYMODE_OK : (int)e;
+}
+}  // namespace symode
+
 extern "C" int symode_lbfgs_update(float* params, const float* g, const float* loss, unsigned char* act, long* n_iter, float* d,
                                    float* t, float* old_dirs, float* old_stps, float* ro, long* head, long* count,
                                    float* h_diag, float* prev_g, float* prev_loss, long n_problems, int n, int history,
                                    float lr, float tol_change, void* stream) {
-    using namespace symode;
-    if (n_problems < 1 || n < 1 || n > WAVE * LB_MAXC || history < 1 || history > LB_MAXH) return SYMODE_E_BADSIZE;
-    if (!params || !g || !loss || !act || !n_iter || !d || !t || !old_dirs || !old_stps || !ro || !head || !count || !h_diag ||
-        !prev_g || !prev_loss)
-        return SYMODE_E_NULLPTR;
-    const size_t stage_bytes = ((size_t)2 * n + 1) * history * sizeof(float);
-    if (stage_bytes <= 60 * 1024)
-        lbfgs_update_kernel<true><<<dim3((unsigned)n_problems), dim3(WAVE), stage_bytes, (hipStream_t)stream>>>(
-            params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history, lr,
-            tol_change);
-    else
-        lbfgs_update_kernel<false><<<dim3((unsigned)n_problems), dim3(WAVE), 0, (hipStream_t)stream>>>(
-            params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history, lr,
-            tol_change);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SYMODE_OK : (int)e;
+    return symode::launch_lbfgs_update(false, params, const_cast<float*>(g), const_cast<float*>(loss), act, n_iter, d, t, old_dirs,
+                                       old_stps, ro, head, count, h_diag, prev_g, prev_loss, n_problems, n, history, lr, tol_change,
+                                       symode::AcceptArgs{nullptr, nullptr, 0.0f, 0, 1.0f, 0.0f}, stream);
+}
+
+extern "C" int symode_lbfgs_accept_update(const float* new_loss, const float* new_g, float tol_grad, int l1, float w_x, float w_reg,
+                                          float* params, float* g, float* loss, unsigned char* act, long* n_iter, float* d,
+                                          float* t, float* old_dirs, float* old_stps, float* ro, long* head, long* count,
+                                          float* h_diag, float* prev_g, float* prev_loss, long n_problems, int n, int history,
+                                          float lr, float tol_change, void* stream) {
+    return symode::launch_lbfgs_update(true, params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g,
+                                       prev_loss, n_problems, n, history, lr, tol_change,
+                                       symode::AcceptArgs{new_loss, new_g, tol_grad, l1, w_x, w_reg}, stream);
 }
 
 extern "C" int symode_lbfgs_accept(const float* new_loss, const float* new_g, float* loss, float* g, unsigned char* act,

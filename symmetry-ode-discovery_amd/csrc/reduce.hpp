@@ -39,6 +39,12 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return v;
 }
 
+// ... and as a scalar: every lane holds the total, the compiler just cannot know; handing it back through
+// v_readfirstlane keeps everything computed from it (step coefficients, loop bounds, branch conditions) on the scalar side.
+__device__ __forceinline__ float wave_sum_dpp_uniform(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum_dpp(v))));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);

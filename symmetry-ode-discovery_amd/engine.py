@@ -64,6 +64,8 @@ _SIGNATURES = {
                                        c_int, c_void_p, c_void_p]),
     "symode_selftest_wave_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "symode_lbfgs_update": (c_int, [c_void_p] * 15 + [c_long, c_int, c_int, c_float, c_float, c_void_p]),
+    "symode_lbfgs_accept_update": (c_int, [c_void_p, c_void_p, c_float, c_int, c_float, c_float] + [c_void_p] * 15
+                                   + [c_long, c_int, c_int, c_float, c_float, c_void_p]),
     "symode_lbfgs_accept": (c_int, [c_void_p] * 8 + [c_long, c_int, c_float, c_float, c_void_p, c_float, c_float, c_void_p]),
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
@@ -552,6 +554,19 @@ class HipEngine:
                                                  self._ptr(st.old_stps), self._ptr(st.ro), self._ptr(st.head), self._ptr(st.hist),
                                                  self._ptr(st.H_diag), self._ptr(st.prev_g), self._ptr(st.prev_loss), S, n, H,
                                                  float(lr), float(tol_change), self._stream(params)), "symode_lbfgs_update")
+
+    def lbfgs_accept_update(self, new_loss, new_g, params, g, loss, act, st, lr, tol_grad, tol_change, l1=None):
+        """lbfgs_accept followed by lbfgs_update in ONE launch (state tensors checked by the preceding lbfgs_update call of
+        the same optimiser step).  ``l1 = (w_x, w_reg)``: new_loss / new_g are the bare data term."""
+        S, n = params.shape
+        new_loss, new_g = self._dev(new_loss, "new_loss"), self._dev(new_g, "new_g")
+        w_x, w_reg = (1.0, 0.0) if l1 is None else l1
+        self._check(self.lib.symode_lbfgs_accept_update(
+            self._ptr(new_loss), self._ptr(new_g), float(tol_grad), 0 if l1 is None else 1, float(w_x), float(w_reg),
+            self._ptr(params), self._ptr(g), self._ptr(loss), self._ptr(act), self._ptr(st.n_iter), self._ptr(st.d), self._ptr(st.t),
+            self._ptr(st.old_dirs), self._ptr(st.old_stps), self._ptr(st.ro), self._ptr(st.head), self._ptr(st.hist),
+            self._ptr(st.H_diag), self._ptr(st.prev_g), self._ptr(st.prev_loss), S, n, st.old_dirs.shape[1], float(lr),
+            float(tol_change), self._stream(params)), "symode_lbfgs_accept_update")
 
     def lbfgs_accept(self, new_loss, new_g, loss, g, act, st, tol_grad, tol_change, l1=None):
         """In place: moved problems take the re-evaluated loss / gradient and run the stopping tests; ``act``: moved in,

@@ -133,8 +133,10 @@ class BatchedLBFGS:
         self.use_graph = bool(use_graph and params.is_cuda and self.engine is not None)
         # the whole optimiser side of an iteration as two kernels (symode_lbfgs_update / _accept), a wave per problem
         self.data_term = None          # (closure of the bare data term, w_x, w_reg): objective = w_x * data + w_reg * |P|_1
+        self.merged = False            # accept + next update as one launch (set below)
         self.fused = bool(self.engine is not None and hasattr(self.engine, 'lbfgs_update') and dt == torch.float32
                           and params.is_contiguous() and os.environ.get('SYMODE_LBFGS_FUSED', '1') != '0')
+        self.merged = bool(self.fused and hasattr(self.engine, 'lbfgs_accept_update') and os.environ.get('SYMODE_LBFGS_MERGED', '1') != '0')
         self._graph, self._graph_closure, self._warm = None, None, 0
 
     def reset(self, which):
@@ -223,6 +225,36 @@ class BatchedLBFGS:
             live = live & ~stop
         act.copy_(live)
 
+    def _evaluate_accept_update(self, closure):
+        """closure at the moved parameters, then ONE optimiser launch: finish the running iteration (accept + stopping
+        tests) and start the next one (update + move) for the problems still active."""
+        if self.data_term is not None:
+            raw, w_x, w_reg = self.data_term
+            nl, ng = raw(self.P)
+            l1 = (w_x, w_reg)
+        else:
+            nl, ng = closure(self.P)
+            l1 = None
+        self.engine.lbfgs_accept_update(nl, ng, self.P, self._g, self._loss, self._act, self, self.lr, self.tol_g, self.tol_c, l1=l1)
+
+    def _replayed(self, body, closure):
+        """``body(closure)`` is a handful of launches on persistent buffers: after a few eager runs (lazy initialisations
+        done) it is captured ONCE in a HIP graph and replayed -- same kernels, same buffers."""
+        if self._graph is None or self._graph_closure is not closure:
+            if self._warm < 3 or (self._graph is not None and self._graph_closure is not closure):
+                self._warm += 1
+                return body(closure)
+            try:
+                torch.cuda.synchronize(self.P.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body(closure)
+                self._graph, self._graph_closure = graph, closure
+            except Exception:                                              # pragma: no cover - depends on the runtime
+                self.use_graph = False
+                return body(closure)
+        self._graph.replay()
+
     def _iteration_replayed(self, closure):
         """The iteration is ~60 small launches around one fused closure kernel: launch-bound.  After a few eager runs
         (lazy initialisations done) it is captured ONCE in a HIP graph and replayed -- same kernels, same buffers."""
@@ -251,6 +283,18 @@ class BatchedLBFGS:
         if frozen is not None:
             act = act & ~frozen
         self._act.copy_(act)
+        if self.merged:
+            # iteration 1's update alone, then (closure, accept + next update) max_iter - 1 times: the last update is the
+            # one torch performs without re-evaluating (n_iter == max_iter)
+            self.engine.lbfgs_update(self.P, self._g, self._loss, self._act, self, self.lr, self.tol_c)
+            for it in range(1, self.max_iter):
+                if self.use_graph:
+                    self._replayed(self._evaluate_accept_update, closure)
+                else:
+                    self._evaluate_accept_update(closure)
+                if it % 5 == 0 and not bool(self._act.any()):               # the only host sync, every 5th iteration
+                    break
+            return self._loss.clone()
         for it in range(1, self.max_iter + 1):
             if it == self.max_iter:
                 self._iteration(closure, False)

@@ -295,15 +295,18 @@ def test_fused_lbfgs_iteration_matches_the_tensor_op_form_and_torch(S, monkeypat
             return 0.5 * (Pm * AP).sum(1) - (bd * Pm).sum(1), AP - bd
 
         runs = {}
-        for fused in ("1", "0"):
+        for mode, fused, merged in (("merged", "1", "1"), ("two", "1", "0"), ("ops", "0", "0")):
             monkeypatch.setenv("SYMODE_LBFGS_FUSED", fused)
+            monkeypatch.setenv("SYMODE_LBFGS_MERGED", merged)
             P = P0.to(DEV).clone()
             opt = BatchedLBFGS(P, lr, history_size=H, engine=eng)
-            assert opt.fused == (fused == "1")
+            assert opt.fused == (fused == "1") and opt.merged == (merged == "1")
             losses = [opt.step(batched).cpu() for _ in range(steps)]
-            runs[fused] = (P.cpu(), torch.stack(losses), opt.n_iter.cpu(), opt.hist.cpu(), opt.head.cpu())
-        Pf, Lf, nf, hf, hdf = runs["1"]
-        Pt, Lt, nt, ht, hdt = runs["0"]
+            runs[mode] = (P.cpu(), torch.stack(losses), opt.n_iter.cpu(), opt.hist.cpu(), opt.head.cpu())
+        # accept + update as one launch vs as two: the same arithmetic on the same values
+        assert torch.equal(runs["merged"][0], runs["two"][0]) and torch.equal(runs["merged"][2], runs["two"][2]), n
+        Pf, Lf, nf, hf, hdf = runs["merged"]
+        Pt, Lt, nt, ht, hdt = runs["ops"]
         # (where a problem converges to the last bit the stopping tests fire an iteration or two apart: only the problem
         # that starts at its optimum is pinned on its count)
         assert int(nf[1]) == int(nt[1]) and int(nf[1]) < 20 * steps, (n, nf, nt)
@@ -357,9 +360,11 @@ def test_seed_sweep_with_fused_optimiser_kernels_equals_the_tensor_op_sweep(S, g
     ]
     for name, make, P0, epochs in cases:
         out = {}
-        for fused in ("1", "0"):
-            monkeypatch.setenv("SYMODE_LBFGS_FUSED", fused)
+        for fused in ("1", "2", "0"):                    # "2": accept and update as separate launches
+            monkeypatch.setenv("SYMODE_LBFGS_FUSED", "0" if fused == "0" else "1")
+            monkeypatch.setenv("SYMODE_LBFGS_MERGED", "1" if fused == "1" else "0")
             out[fused] = make().fit(P0, epochs)
+        assert torch.equal(out["1"]["mask"], out["2"]["mask"]) and torch.equal(out["1"]["params"], out["2"]["params"]), name
         a, b = out["1"], out["0"]
         assert torch.equal(a["mask"], b["mask"]), name
         assert torch.equal(a["finished"], b["finished"]) and torch.equal(a["nan"], b["nan"]), name
