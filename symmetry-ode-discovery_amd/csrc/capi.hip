@@ -39,9 +39,18 @@ inline int gram_grid(long n, long S) {
     return (int)(g > cap ? cap : g);
 }
 
-inline int small_grid_cap() {
+// Workgroups of ONE closure problem (the last of them adds the partial rows alone; all of them stream one moving window
+// of memory): measured best counts (profiles/r02_single_grid.txt, us per launch at cap 128 / 256 / 512 / round-2 default):
+//   Theta + residual + grad, 16 B/point:   1 M points 10.5 / 11.4 / 15.7 / 10.3    4 M  19.0 / 16.5 / 20.5 / 30.0
+//                                          16 M       58.8 / 44.9 / 48.3 / 51.6    64 M  211 / 169.5 / 175 / 195.5
+//   fused with the regulariser, 40 B/point: 1 M       24.5 / 17.1 / 17.8 / 24.7    4 M  80.7 / 47.0 / 36.9 / 43.5
+//                                          16 M        308 /  170 /  113 /  118    64 M 1195 /  645 /  432 /  447
+// SYMODE_SMALL_GRID fixes the cap for tuning runs (0 = none).
+inline int small_grid_cap(long n, bool with_regulariser) {
     const char* e = getenv("SYMODE_SMALL_GRID");
-    return e ? atoi(e) : 128;
+    if (e) return atoi(e);
+    if (with_regulariser) return n <= 300000 ? 128 : (n <= 1500000 ? 256 : 512);
+    return n <= 1500000 ? 128 : 256;
 }
 
 // The vector-pipe Gram (gram_valu.hpp) holds two workgroups per CU (register-bound): one balanced round of them for a
@@ -188,8 +197,8 @@ int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, i
     int gx = grid_x_for(n, n_problems, ppt_for(d));
     // a single latency-bound problem: the last workgroup adds gx partial rows alone, so fewer, longer workgroups win
     // (SYMODE_SMALL_GRID overrides the cap for tuning runs; 0 = no cap)
-    if (n_problems == 1 && gx <= 512) {
-        const int cap = small_grid_cap();
+    if (n_problems == 1) {
+        const int cap = small_grid_cap(n, false);
         if (cap > 0 && gx > cap) gx = cap;
     }
     return (int)ops->loss_grad(x, dx, n_problems, n, xi, mask, inv_count, loss_out, grad_out, (double*)workspace, gx,
@@ -243,11 +252,9 @@ int symode_symreg_reversed_batched(const float* x, const float* gx_, const float
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
     int gx = grid_x_for(n, n_problems, ppt_for(d));
-    if (n_problems == 1 && gx <= 512) {
-        const int cap = small_grid_cap();
+    if (n_problems == 1) {
+        const int cap = small_grid_cap(n, true);
         if (cap > 0 && gx > cap) gx = cap;
-    } else if (n_problems == 1) {
-        gx = single_problem_grid(gx, 1024);
     }
     return (int)ops->symreg_reversed(x, nullptr, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, 1.0f, loss_out, grad_out,
                                      (double*)workspace, gx, (hipStream_t)stream);
@@ -264,11 +271,9 @@ int symode_loss_grad_reversed(const float* x, const float* dx, const float* gx_,
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
     int gx = grid_x_for(n, n_problems, ppt_for(d));
-    if (n_problems == 1 && gx <= 512) {
-        const int cap = small_grid_cap();
+    if (n_problems == 1) {
+        const int cap = small_grid_cap(n, true);
         if (cap > 0 && gx > cap) gx = cap;
-    } else if (n_problems == 1) {
-        gx = single_problem_grid(gx, 1024);
     }
     return (int)ops->symreg_reversed(x, dx, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, w_sym, loss2_out, grad_out,
                                      (double*)workspace, gx, (hipStream_t)stream);
