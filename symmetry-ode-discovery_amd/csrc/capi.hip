@@ -70,14 +70,18 @@ inline int gram_valu_grid(long n, long S, int d) {
     return (int)g;
 }
 
-// One large problem through a reduction kernel: the workgroups loop over the data with a grid-wide stride, so all of
-// them read one moving window of memory -- and fewer, longer-lived workgroups keep that window (and the DRAM pages under
-// it) tighter.  Measured at 2^26 points, d = 2, order 3 (fraction of the HBM roof at 512 / 1024 / 2048 workgroups):
-// vjp without grad_x 0.82 / 0.77 / 0.63, jvp_vjp 0.67 / 0.60 / 0.61, symreg_reversed 0.33 / 0.78 / 0.75 (its 4 waves per
-// SIMD need 1024 to cover the latency).  SYMODE_REDUCE_GRID overrides every cap for tuning runs.
-inline int single_problem_grid(int gx, int cap) {
+// One problem through a reduction kernel: the workgroups loop over the data with a grid-wide stride, so all of them read
+// one moving window of memory -- fewer, longer-lived workgroups keep that window (and the DRAM pages under it) tighter,
+// and the last workgroup has fewer partial rows to add.  The best count grows with the problem
+// (profiles/r02_single_grid.txt, us per launch at 64 / 128 / 256 / 512 / 1024 workgroups, d = 2, order 3):
+//   125 000 points  vjp 7.8 / 8.2 / 13.3 / 13.2 / 13.2      jvp_vjp 8.5 / 8.4 / 13.8 / 13.3 / 13.3
+//   1 M             vjp 18.2 / 13.8 / 13.2 / 16.8 / 16.7    jvp_vjp 31.5 / 21.0 / 17.2 / 21.3 / 21.5
+//   8 M             vjp 181 / 103 / 61 / 45.8 / 48.8        jvp_vjp 205 / 112 / 70.2 / 79.3 / 118
+//   64 M            vjp 1461 / 780 / 436 / 310 / 289        jvp_vjp 1605 / 841 / 495 / 572 / 561
+// hence a cap per size class: <= 300 K points, <= 2 M, <= 16 M, beyond.  SYMODE_REDUCE_GRID overrides it for tuning runs.
+inline int single_problem_grid(int gx, long n, int c_small, int c_mid, int c_large, int c_huge) {
     static const int env = getenv("SYMODE_REDUCE_GRID") ? atoi(getenv("SYMODE_REDUCE_GRID")) : 0;
-    const int c = env > 0 ? env : cap;
+    const int c = env > 0 ? env : (n <= 300000 ? c_small : n <= 2000000 ? c_mid : n <= 16000000 ? c_large : c_huge);
     return gx > c ? c : gx;
 }
 
@@ -236,7 +240,7 @@ int symode_symreg_linear(const float* z, long n, int d, int order, int flags, co
     if (!z || !xi || !loss_out || !grad_out || (n_gen > 0 && !L)) return SYMODE_E_NULLPTR;
     if (misaligned(z, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(L, 4)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), 1024);
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 512, 1024);
     return (int)ops->symreg_linear(z, n, xi, mask, L, n_gen, loss_out, grad_out, (double*)workspace, gx,
                                    (hipStream_t)stream);
 }
@@ -312,7 +316,8 @@ int symode_vjp(const float* x, const float* g, long n, int d, int order, int fla
         misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), grad_x ? 1024 : 512);
+    const int gx = grad_x ? single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 512, 1024)
+                          : single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 128, 512, 512);
     return (int)ops->vjp(x, g, n, xi, mask, grad_x, grad_xi, (double*)workspace, gx, (hipStream_t)stream);
 }
 
@@ -338,7 +343,7 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
         misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), 512);
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 256, 256);
     return (int)ops->jvp_vjp(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, grad_xi, (double*)workspace, gx,
                              (hipStream_t)stream);
 }

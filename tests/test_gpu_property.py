@@ -102,9 +102,12 @@ def test_fused_closure_and_reversed_regulariser_random(eng, lib, sine, exp, n, S
         gsym, = torch.autograd.grad(sym, W)
         assert np.isclose(loss2[s, 0].item(), mse.item(), rtol=5e-5, atol=1e-9) and np.isclose(loss2[s, 1].item(), sym.item(), rtol=5e-5, atol=1e-9)
         assert np.isclose(ls[s].item(), sym.item(), rtol=5e-5, atol=1e-9)
-        scale = max((gm * mask[s]).abs().max().item(), 1e-6)
+        # yardstick: the gradient's own size, floored at 1e-4 -- the summands are O(0.01-1) fp32 numbers, and where the
+        # regulariser's gradient nearly cancels (1-d libraries, g close to the identity: |grad| ~ 4e-5) the fp32 sums are
+        # exact to ~4e-9 absolute, not to 5e-5 of the cancelled result
+        scale = max((gm * mask[s]).abs().max().item(), 1e-4)
         assert (grad[s].cpu().double() - gm * mask[s]).abs().max().item() <= 5e-5 * scale
-        scale = max((gsym * mask[s]).abs().max().item(), 1e-6)
+        scale = max((gsym * mask[s]).abs().max().item(), 1e-4)
         assert (gs[s].cpu().double() - gsym * mask[s]).abs().max().item() <= 5e-5 * scale
 
 
