@@ -35,7 +35,10 @@ inline int gram_grid(long n, long S) {
         return v < 2 ? 2 : v;
     }();
     const long g = grid_x_by_points(n, 1);
-    const long cap = S >= total / 2 ? 2 : total / S;
+    long cap = S >= total / 2 ? 2 : total / S;
+    // one problem: the single finalize block adds every partial (6 KB each at two tiles): 125 000 points cost 84 us on
+    // 1024 workgroups, 34 us on 128; 1 M points 178 vs 83 us on 256; 16 M 596 vs 564 us on 512 (r02_single_grid.txt)
+    if (S == 1 && !getenv("SYMODE_GRAM_GRID")) cap = n <= 300000 ? 128 : n <= 2000000 ? 256 : n <= 32000000 ? 512 : total;
     return (int)(g > cap ? cap : g);
 }
 
@@ -94,7 +97,7 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
     const int T = (F + 15) / 16;
     const size_t gram_partial = (size_t)(T * (T + 1) / 2) * 256;
     const size_t nacc = 2 + (size_t)ops->d * ops->p;          // widest row: the fused closure keeps two scalar sums
-    size_t g_red = (size_t)grid_x_for(n, S, 1);         // widest grid any reduction uses
+    size_t g_red = (size_t)grid_x_for(n, S, 1, 512);    // widest grid any reduction uses
     if ((size_t)gram_grid(n, S) > g_red) g_red = (size_t)gram_grid(n, S);
     if ((size_t)gram_valu_grid(n, S, ops->d) > g_red) g_red = (size_t)gram_valu_grid(n, S, ops->d);
     const size_t a = (size_t)S * g_red * nacc;
@@ -255,7 +258,7 @@ int symode_symreg_reversed_batched(const float* x, const float* gx_, const float
         misaligned(loss_out, 4) || misaligned(grad_out, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
-    int gx = grid_x_for(n, n_problems, ppt_for(d));
+    int gx = grid_x_for(n, n_problems, ppt_for(d), 512);
     if (n_problems == 1) {
         const int cap = small_grid_cap(n, true);
         if (cap > 0 && gx > cap) gx = cap;
@@ -274,7 +277,7 @@ int symode_loss_grad_reversed(const float* x, const float* dx, const float* gx_,
         misaligned(loss2_out, 4) || misaligned(grad_out, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
-    int gx = grid_x_for(n, n_problems, ppt_for(d));
+    int gx = grid_x_for(n, n_problems, ppt_for(d), 512);
     if (n_problems == 1) {
         const int cap = small_grid_cap(n, true);
         if (cap > 0 && gx > cap) gx = cap;

@@ -23,11 +23,13 @@ constexpr int MAP_CHUNKS_PER_THREAD = SYMODE_MAP_CHUNKS;   // chunks a thread of
 //   16 x 125 000: 11.9 / 18.1 / 55.3     64 x 50 000: 11.4 / 13.4 / 64.9     256 x 50 000: 32.4 / 35.0 / 70.1
 //   512 x 125 000 and up: the floor of two workgroups per problem decides (162-178 us either way).
 // SYMODE_MAX_GRID fixes the budget for tuning runs; SYMODE_MIN_GRID_X the floor per problem.
-inline long batch_grid_budget(long total_points) {
+// The fused closure (40 B/point, 3-4 waves per SIMD) wants twice the floor: 16 x 125 000: 26.6 us at 256, 22.4 at 512, 37.0
+// at 2048; 64 x 50 000: 38.0 / 27.3 / 36.5 (profiles/r02_batched_grid.txt).
+inline long batch_grid_budget(long total_points, long floor_) {
     static const long fixed = getenv("SYMODE_MAX_GRID") ? atol(getenv("SYMODE_MAX_GRID")) : 0;
     if (fixed > 0) return fixed < 2 ? 2 : fixed;
     long b = total_points / 16384;
-    if (b < 256) b = 256;
+    if (b < floor_) b = floor_;
     if (b > 1024) b = 1024;
     return b;
 }
@@ -91,11 +93,11 @@ inline long grid_x_by_points(long n, int pts_per_thread_iter) {
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
 }
 
-inline int grid_x_for(long n, long S, int pts_per_thread_iter) {
+inline int grid_x_for(long n, long S, int pts_per_thread_iter, long batch_floor = 256) {
     long g = grid_x_by_points(n, pts_per_thread_iter);
     long cap = 2048;                   // one problem: the last workgroup adds the partial rows alone, keep them few
     if (S > 1) {
-        cap = batch_grid_budget(n * S) / S;
+        cap = batch_grid_budget(n * S, batch_floor) / S;
         if (cap < min_grid_x()) cap = min_grid_x();
     }
     if (g > cap) g = cap;
