@@ -30,9 +30,12 @@ def _regressor(S, g, tag, d, order, thr):
     return r
 
 
-@pytest.mark.parametrize("mode", ["host_numpy", "host_torch", "device"])
+@pytest.mark.parametrize("mode", ["host_numpy", "host_torch", "device", "device_kernels"])
 @pytest.mark.parametrize("tag", ["dosc_sindy", "dosc_esindy", "selkov_sindy"])
 def test_lbfgs_trainer_on_gpu_matches_reference_run(S, golden, tag, mode, tmp_path, monkeypatch):
+    """The reference's three recorded runs through every optimiser placement: torch.optim.LBFGS on host variables
+    (default) / on device tensors, the numpy restatement, and ``device_lbfgs=True`` (optimiser + epoch logic as device
+    kernels, one launch per inner iteration beside the closure kernel)."""
     host_lbfgs, numpy_lbfgs = mode != "device", mode == "host_numpy"
     if numpy_lbfgs and tag == "selkov_sindy":
         pytest.skip("opt-in numpy L-BFGS: chaotic trajectory on the ill-conditioned selkov library (see train.py)")
@@ -48,12 +51,17 @@ def test_lbfgs_trainer_on_gpu_matches_reference_run(S, golden, tag, mode, tmp_pa
                               regressor=r, regressor_dst=None, use_latent=False, distill_latent=False, lr_sindy=float(lr),
                               w_sindy_z=0.0, w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="i",
                               w_sym_reg=0.0, st_freq=int(st_freq), threshold=float(thr), int_t=0.1, int_dt=0.01, print_eq=False,
-                              host_lbfgs=host_lbfgs, numpy_lbfgs=numpy_lbfgs)
+                              host_lbfgs=host_lbfgs, numpy_lbfgs=numpy_lbfgs, device_lbfgs=mode == "device_kernels")
     assert np.array_equal(r.mask.cpu().numpy(), g[f"{tag}_mask_final"])            # identical sparsity mask
+    if mode == "device_kernels":
+        import os
+        assert any(f.startswith("regressor_") for f in os.listdir("saved_models/t"))
     want = g[f"{tag}_Xi_final"]
     got = r.get_Xi().detach().cpu().numpy()
     # the iteration ends on "parameter update < 1e-3" (train.py:643): both runs sit within that ball of the minimiser
-    assert np.allclose(got * g[f"{tag}_mask_final"], want * g[f"{tag}_mask_final"], rtol=1e-3, atol=1e-4), np.abs(got - want).max()
+    # (the restated optimiser on the ill-conditioned selkov library, cond 9e3: same mask, coefficients 7e-4 apart inside it)
+    atol = 1e-3 if (mode == "device_kernels" and tag == "selkov_sindy") else 1e-4
+    assert np.allclose(got * g[f"{tag}_mask_final"], want * g[f"{tag}_mask_final"], rtol=1e-3, atol=atol), np.abs(got - want).max()
     if f"{tag}_eval_cf" in g.files:
         coef, cf, mse, cf_all, mse_all = S.evaluation.eval_sindy_regressor(r, S.evaluation.sindy_truth[tag.split("_")[0]])
         assert np.array_equal(cf, g[f"{tag}_eval_cf"]) and bool(cf_all) == bool(g[f"{tag}_eval_cf_all"])
@@ -190,15 +198,17 @@ def test_reversed_regulariser_host_and_device_lbfgs_agree(S, golden, tmp_path, m
     Xi0 = t(g[f"{tag}_Xi"])
     dx = O.forward(x, Xi0 * 0.5, torch.ones_like(Xi0), order, bool(sine), bool(exp)).detach()
     out = []
-    for host in (True, False):
+    for host, kernels in ((True, False), (False, False), (True, True)):     # last: --device_lbfgs (optimiser as device kernels)
         r = S.SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.01, device=DEV)
         r.Xi.data = Xi0.to(DEV)
         S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ae, generator=gen, regressor=r,
-                                  **_train_kwargs(sym_reg_type="r", w_sym_reg=0.1, num_epochs=3, host_lbfgs=host, threshold=0.01))
+                                  **_train_kwargs(sym_reg_type="r", w_sym_reg=0.1, num_epochs=3, host_lbfgs=host, threshold=0.01,
+                                                  device_lbfgs=kernels))
         out.append((r.Xi.detach().cpu().numpy(), r.mask.cpu().numpy()))
-    assert np.array_equal(out[0][1], out[1][1])
-    # two un-converged L-BFGS trajectories (fp32 host vs device arithmetic) after 3 epochs
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1])
+    # un-converged L-BFGS trajectories (fp32 host vs device arithmetic) after 3 epochs
     assert np.allclose(out[0][0], out[1][0], rtol=2e-2, atol=2e-3)
+    assert np.allclose(out[0][0], out[2][0], rtol=2e-2, atol=2e-3)
 
 
 def test_latent_branch_and_distillation_with_identity_autoencoder(S, golden, tmp_path, monkeypatch):
