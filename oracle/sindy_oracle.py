@@ -68,7 +68,7 @@ def theta(x: torch.Tensor, order: int, include_sine: bool = False, include_exp: 
     multiply, which is what makes the polynomial columns bit-reproducible.
     """
     d = x.shape[-1]
-    blocks = [torch.ones(*x.shape[:-1], 1), x]                      # sindy.py:7-11
+    blocks = [torch.ones(*x.shape[:-1], 1, dtype=x.dtype, device=x.device), x]     # sindy.py:7-11 (ones on x's device)
     prev = {(i,): x[..., i] for i in range(d)}
     for n in range(2, order + 1):
         cur, cols = {}, []

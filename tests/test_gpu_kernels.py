@@ -704,3 +704,52 @@ def test_dpp_wave_sum_is_bit_identical_to_the_shuffle_butterfly(eng):
         torch.cuda.synchronize()
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
         assert torch.allclose(a.view(-1, 64)[:, 0], data.view(-1, 64).double().sum(1).float(), rtol=1e-4, atol=1e-4 * data.abs().max().item())
+
+
+@pytest.mark.parametrize("n", [299_999, 300_001, 1_500_001, 2_000_003])
+def test_single_problem_launch_size_classes_vs_fp64(eng, n):
+    """The workgroup cap of a single-problem reduction launch changes with the problem's size class (capi.hip:
+    small_grid_cap / single_problem_grid; class edges at 300 K, 1.5 M, 2 M points).  Either side of every edge: loss and
+    gradient of the closure, the fused closure, the regulariser alone, vjp (both outputs) and the linear-latent
+    regulariser against an fp64 evaluation of the oracle's op sequence (torch ops on the GPU: same formulas, wider type)."""
+    d, order, p = 2, 3, 10
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, d, device="cuda", generator=gen) * 0.6
+    dx = torch.randn(n, d, device="cuda", generator=gen)
+    g = torch.randn(n, d, device="cuda", generator=gen)
+    gx = x + 0.05 * torch.randn(n, d, device="cuda", generator=gen)
+    jg = torch.eye(d, device="cuda") + 0.05 * torch.randn(n, d, d, device="cuda", generator=gen)
+    Xi = (torch.randn(d, p, generator=torch.Generator().manual_seed(3)) * 0.3).cuda()
+    L = torch.tensor([[[0.0, 1.0], [-1.0, 0.0]]], device="cuda")
+
+    W = Xi.double().requires_grad_(True)
+    xd = x.double().requires_grad_(True)
+    h = lambda a: O.theta(a, order) @ W.T  # noqa: E731
+    hx = h(xd)
+    mse = ((hx - dx.double()) ** 2).mean()
+    sym = ((torch.einsum("bij,bj->bi", jg.double(), hx) - h(gx.double())) ** 2).mean()
+    g_mse, = torch.autograd.grad(mse, W, retain_graph=True)
+    g_sym, = torch.autograd.grad(sym, W, retain_graph=True)
+    gW, gX = torch.autograd.grad((hx * g.double()).sum(), (W, xd))
+
+    loss, grad = eng.loss_grad(x, dx, Xi, None, order)
+    assert np.isclose(loss.item(), mse.item(), rtol=2e-5)
+    assert_close_scaled(grad.cpu().numpy(), g_mse.cpu().numpy(), 2e-5, "loss_grad")
+    l2, gf = eng.loss_grad_reversed(x[None], dx[None], gx[None, None], jg[None, None], Xi[None], None, order, 0, w_sym=0.7)
+    assert np.isclose(l2[0, 0].item(), mse.item(), rtol=2e-5) and np.isclose(l2[0, 1].item(), sym.item(), rtol=2e-5)
+    assert_close_scaled(gf[0].cpu().numpy(), (g_mse + 0.7 * g_sym).cpu().numpy(), 2e-5, "fused closure")
+    ls, gs = eng.symreg_reversed(x, gx[None], jg[None], Xi, None, order)
+    assert np.isclose(ls.item(), sym.item(), rtol=2e-5)
+    assert_close_scaled(gs.cpu().numpy(), g_sym.cpu().numpy(), 2e-5, "symreg_reversed")
+    gxv, gxi = eng.vjp(x, g, Xi, None, order)
+    assert_close_scaled(gxi.cpu().numpy(), gW.cpu().numpy(), 2e-5, "vjp grad_xi")
+    assert_close_scaled(gxv.cpu().numpy(), gX.cpu().numpy(), 1e-5, "vjp grad_x")
+    _, gxi2 = eng.vjp(x, g, Xi, None, order, need_grad_x=False)
+    assert_close_scaled(gxi2.cpu().numpy(), gW.cpu().numpy(), 2e-5, "vjp grad_xi (no grad_x)")
+    del hx, mse, sym, gW, gX
+    W2 = Xi.double().requires_grad_(True)
+    s1 = O.symreg_linear_latent(x.double(), [L[0].double()], lambda a: O.theta(a, order) @ W2.T)
+    g1, = torch.autograd.grad(s1, W2)
+    l1, gr1 = eng.symreg_linear(x, Xi, None, L, order)
+    assert np.isclose(l1.item(), s1.item(), rtol=2e-5)
+    assert_close_scaled(gr1.cpu().numpy(), g1.cpu().numpy(), 2e-5, "symreg_linear")
