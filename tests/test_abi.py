@@ -107,6 +107,39 @@ def test_argument_validation_of_the_round2_entries(lib):
     assert f(good, 8, 2, 3, 0, good, good, 4, good, good, 512, null) == -4
 
 
+def test_argument_validation_of_the_lbfgs_iteration_entries(lib):
+    """symode_lbfgs_update / _accept / _accept_update / symode_selftest_wave_sum: sizes and null pointers are refused
+    before any launch (n <= 256 parameters, history <= 128 pairs)."""
+    null = ctypes.c_void_p(None)
+    buf = (ctypes.c_double * 64)()
+    good = ctypes.cast(buf, ctypes.c_void_p)
+    st = [good] * 15                     # params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss
+    f = lib.symode_lbfgs_update
+    assert f(*st, 0, 20, 100, 1.0, 1e-9, null) == -3
+    assert f(*st, 4, 257, 100, 1.0, 1e-9, null) == -3
+    assert f(*st, 4, 20, 129, 1.0, 1e-9, null) == -3
+    assert f(*st, 4, 0, 100, 1.0, 1e-9, null) == -3
+    for k in range(15):
+        args = list(st)
+        args[k] = null
+        assert f(*args, 4, 20, 100, 1.0, 1e-9, null) == -2, k
+    f = lib.symode_lbfgs_accept        # new_loss, new_g, loss, g, act, d, t, prev_loss, S, n, tol_grad, tol_change, params, w_x, w_reg, stream
+    assert f(*([good] * 8), 0, 20, 1e-7, 1e-9, null, 1.0, 0.0, null) == -3
+    assert f(*([good] * 8), 4, 300, 1e-7, 1e-9, null, 1.0, 0.0, null) == -3
+    for k in range(8):
+        args = [good] * 8
+        args[k] = null
+        assert f(*args, 4, 20, 1e-7, 1e-9, null, 1.0, 0.0, null) == -2, k
+    f = lib.symode_lbfgs_accept_update  # new_loss, new_g, tol_grad, l1, w_x, w_reg, <15 state pointers>, S, n, history, lr, tol_change, stream
+    assert f(good, good, 1e-7, 0, 1.0, 0.0, *st, 4, 20, 0, 1.0, 1e-9, null) == -3
+    assert f(good, good, 1e-7, 0, 1.0, 0.0, *st, -1, 20, 100, 1.0, 1e-9, null) == -3
+    assert f(null, good, 1e-7, 0, 1.0, 0.0, *st, 4, 20, 100, 1.0, 1e-9, null) == -2
+    assert f(good, null, 1e-7, 0, 1.0, 0.0, *st, 4, 20, 100, 1.0, 1e-9, null) == -2
+    assert f(good, good, 1e-7, 1, 1.0, 0.0, *([null] + st[1:]), 4, 20, 100, 1.0, 1e-9, null) == -2
+    f = lib.symode_selftest_wave_sum
+    assert f(good, good, good, 0, null) == -3 and f(null, good, good, 1, null) == -2
+
+
 def test_engine_refuses_cpu_tensors():
     import torch
     eng = symode_amd.get_engine()
