@@ -1,0 +1,34 @@
+"""cProfile of the single-seed driver (symode_amd.main.main) on the reference's config names, second run (data files
+exist, kernels warm):  python tools/micro/e2e_profile.py dosc/noise20_sindy.cfg [extra main args ...]"""
+import cProfile, io, os, pstats, shutil, sys, tempfile, time, contextlib
+sys.path.insert(0, os.getcwd())
+import torch
+import symode_amd.main as M
+
+cfg = sys.argv[1]
+extra = sys.argv[2:]
+work = tempfile.mkdtemp(prefix="e2e_")
+shutil.copytree(os.path.join(os.path.dirname(os.path.abspath(M.__file__)), "run_configs"), os.path.join(work, "run_configs"))
+os.chdir(work)
+argv = ["--seed", "0", "--config", cfg, "--gpu", "0"] + extra
+if os.environ.get("E2E_PREP"):                      # e.g. E2E_PREP="lv/noise99_sym.cfg --num_epochs 1": a run whose outputs cfg loads
+    prep = os.environ["E2E_PREP"].split()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        M.main(["--seed", "0", "--config", prep[0], "--gpu", "0"] + prep[1:])
+    print(f"prep {' '.join(prep)}: {time.perf_counter() - t0:.2f} s", flush=True)
+for rep in range(2):
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        pr.enable()
+        M.main(list(argv))
+        torch.cuda.synchronize()
+        pr.disable()
+    dt = time.perf_counter() - t0
+    print(f"{cfg} {' '.join(extra)} run {rep}: {dt:.3f} s", flush=True)
+st = io.StringIO()
+pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
+print("\n".join(l[:170] for l in st.getvalue().splitlines()[:75]))
