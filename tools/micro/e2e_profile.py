@@ -3,7 +3,8 @@ exist, kernels warm):  python tools/micro/e2e_profile.py dosc/noise20_sindy.cfg 
 import cProfile, io, os, pstats, shutil, sys, tempfile, time, contextlib
 sys.path.insert(0, os.getcwd())
 import torch
-import symode_amd.main as M
+import importlib
+M = importlib.import_module("symode_amd." + os.environ.get("E2E_MODULE", "main"))     # main | main_sindy | main_wsindy | main_sweep
 
 cfg = sys.argv[1]
 extra = sys.argv[2:]
