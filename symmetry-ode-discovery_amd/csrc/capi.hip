@@ -99,7 +99,7 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
     const size_t nacc = 2 + (size_t)ops->d * ops->p;          // widest row: the fused closure keeps two scalar sums
     size_t g_red = (size_t)grid_x_for(n, S, 1, 512);    // widest grid any reduction uses
     if ((size_t)gram_grid(n, S) > g_red) g_red = (size_t)gram_grid(n, S);
-    if ((size_t)gram_valu_grid(n, S, ops->d) > g_red) g_red = (size_t)gram_valu_grid(n, S, ops->d);
+    if ((size_t)gram_valu_grid(n, S, ops->d) + 8 > g_red) g_red = (size_t)gram_valu_grid(n, S, ops->d) + 8;   // (+8: the split form rounds up)
     const size_t a = (size_t)S * g_red * nacc;
     const size_t b = (size_t)S * g_red * gram_partial;
     return (size_t)WS_HEADER_DOUBLES + (a > b ? a : b);      // [magic + tickets | partial rows]

@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "gram.hpp"
 
 namespace symode {
@@ -161,6 +163,165 @@ __global__ __launch_bounds__(BLOCK) void gram_valu_finalize_kernel(const double*
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 12 < F <= 24 (order 4-5 at d = 2, the d = 3 / d = 4 libraries up to 20 terms): the F(F+1)/2 <= 300 sums do not fit one
+// thread, and a 16x16x4 MFMA tiling spends 768 multiply-adds per point on them (36 % useful at F = 23; gram.hpp: 0.08 of
+// the HBM roof).  The triangle is therefore cut into NPART <= 4 runs of NE <= 78 consecutive entries (row-major), and a
+// WORKGROUP owns one run: every thread evaluates the whole library for its points (fp32, ~20 multiplies at order 5 -- cheap
+// beside NE fp64 FMAs) and accumulates its run only; which run is wave-uniform (a switch over PART with one unrolled body
+// each), so the feature registers are indexed at compile time.  The NPART workgroups that share a slab of points get
+// consecutive-by-8 linear ids -- same XCD, same L2 -- so the slab comes from HBM once.
+// ---------------------------------------------------------------------------------------
+constexpr int pair_row(int F, int q) {
+    int i = 0;
+    while (q >= F - i) {
+        q -= F - i;
+        ++i;
+    }
+    return i;
+}
+constexpr int pair_col(int F, int q) {
+    int i = 0;
+    while (q >= F - i) {
+        q -= F - i;
+        ++i;
+    }
+    return i + q;
+}
+
+template <class Lib>
+struct GramSplitShape {
+    static constexpr int F = Lib::P + Lib::D;
+    static constexpr int NPAIR = F * (F + 1) / 2;
+    static constexpr bool OK = F > 12 && F <= 24;
+    static constexpr int NPART = (NPAIR + 77) / 78;              // 2 .. 4
+    static constexpr int NE = (NPAIR + NPART - 1) / NPART;       // entries per run (the last run may be shorter)
+};
+
+// one entry of a run: (row, col) are template-time constants, so f[] stays in registers
+template <int F, int NPAIR, int Q0, int NE, int E>
+__device__ __forceinline__ void gram_run_one(const double (&f)[F], double (&acc)[NE]) {
+    if constexpr (Q0 + E < NPAIR) {
+        constexpr int I = pair_row(F, Q0 + E), J = pair_col(F, Q0 + E);
+        acc[E] = fma(f[I], f[J], acc[E]);
+    }
+}
+
+template <int F, int NPAIR, int Q0, int NE, int... E>
+__device__ __forceinline__ void gram_run_accumulate(const double (&f)[F], double (&acc)[NE], std::integer_sequence<int, E...>) {
+    (gram_run_one<F, NPAIR, Q0, NE, E>(f, acc), ...);
+}
+
+template <class Lib, int PART>
+__device__ __forceinline__ void gram_split_body(const float* __restrict__ xs, const float* __restrict__ ys, long N, bool vec,
+                                                long tid, long nthreads, double* __restrict__ dst, double* lds) {
+    using G = GramSplitShape<Lib>;
+    constexpr int D = Lib::D, P = Lib::P, F = G::F, NE = G::NE, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV;
+    double acc[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) acc[q] = 0.0;
+    auto one = [&](const float (&xp)[D], const float (&yp)[D]) {
+        float th[P];
+        Lib::eval(xp, th);
+        double f[F];
+#pragma unroll
+        for (int k = 0; k < P; ++k) f[k] = (double)th[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) f[P + j] = (double)yp[j];
+        gram_run_accumulate<F, G::NPAIR, PART * NE, NE>(f, acc, std::make_integer_sequence<int, NE>{});
+    };
+    if (vec) {
+        // one chunk per step, the next one requested before this one's arithmetic (the run's NE fp64 sums and the F fp64
+        // features leave no room for more in flight: 2 waves per SIMD)
+        const long nchunks = N / PPT;
+        long c = tid;
+        float4 ax[NV], ay[NV];
+        if (c < nchunks) {
+            load_chunk_raw<D, false>(xs, c, ax);               // plain loads: the sibling runs read the same lines from L2
+            load_chunk_raw<D, false>(ys, c, ay);
+        }
+        for (; c < nchunks; c += nthreads) {
+            float xa[PPT][D], ya[PPT][D];
+            unpack_chunk<D>(ax, xa);
+            unpack_chunk<D>(ay, ya);
+            if (c + nthreads < nchunks) {
+                load_chunk_raw<D, false>(xs, c + nthreads, ax);
+                load_chunk_raw<D, false>(ys, c + nthreads, ay);
+            }
+#pragma unroll 1
+            for (int i = 0; i < PPT; ++i) one(xa[i], ya[i]);
+        }
+        const long n = nchunks * PPT + tid;
+        if (n < N) {
+            float xp[D], yp[D];
+            load_point<D>(xs, n, xp);
+            load_point<D>(ys, n, yp);
+            one(xp, yp);
+        }
+    } else {
+        for (long n = tid; n < N; n += nthreads) {
+            float xp[D], yp[D];
+            load_point<D>(xs, n, xp);
+            load_point<D>(ys, n, yp);
+            one(xp, yp);
+        }
+    }
+    block_reduce_emit_lds_f64<NE, BLOCK>(acc, lds, [&](int q, double v) { dst[q] = v; });
+}
+
+// grid = (GX * NPART, S), GX a multiple of 8.  Linear id L -> slab column bx = (L % 8) + 8 (L / (8 NPART)), run
+// part = (L / 8) % NPART: the NPART runs of a column sit 8 ids apart (same XCD under round-robin dispatch).
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void aug_gram_split_kernel(const float* __restrict__ x, const float* __restrict__ dx,
+                                                               long N, bool vec, int GX, double* __restrict__ part_ws) {
+    using G = GramSplitShape<Lib>;
+    constexpr int D = Lib::D, NPART = G::NPART, NE = G::NE;
+    __shared__ double lds[reduce_lds_doubles(BLOCK)];
+    const long s = blockIdx.y;
+    const int L = blockIdx.x;
+    const int bx = (L % 8) + 8 * (L / (8 * NPART)), part = (L / 8) % NPART;
+    const float* xs = x + s * N * D;
+    const float* ys = dx + s * N * D;
+    const long tid = (long)bx * BLOCK + threadIdx.x, nthreads = (long)GX * BLOCK;
+    double* dst = part_ws + (((long)s * GX + bx) * NPART + part) * NE;
+    if (part == 0) gram_split_body<Lib, 0>(xs, ys, N, vec, tid, nthreads, dst, lds);
+    if constexpr (NPART > 1) if (part == 1) gram_split_body<Lib, 1>(xs, ys, N, vec, tid, nthreads, dst, lds);
+    if constexpr (NPART > 2) if (part == 2) gram_split_body<Lib, 2>(xs, ys, N, vec, tid, nthreads, dst, lds);
+    if constexpr (NPART > 3) if (part == 3) gram_split_body<Lib, 3>(xs, ys, N, vec, tid, nthreads, dst, lds);
+}
+
+// Sum the GX partial runs of problem s in fixed order and scatter into the dense symmetric (F, F) matrix.
+template <class Lib>
+__global__ __launch_bounds__(BLOCK) void gram_split_finalize_kernel(const double* __restrict__ part_ws, int GX,
+                                                                    double* __restrict__ gram) {
+    using G = GramSplitShape<Lib>;
+    constexpr int F = G::F, NPAIR = G::NPAIR, NPART = G::NPART, NE = G::NE;
+    const long s = blockIdx.x;
+    const double* src = part_ws + s * (long)GX * NPART * NE;
+    double* out = gram + s * (long)F * F;
+    for (int q = threadIdx.x; q < NPAIR; q += BLOCK) {
+        const int part = q / NE, e = q - part * NE;
+        double v = 0.0;
+        int g = 0;
+        for (; g + 8 <= GX; g += 8) {                          // 8 independent loads in flight, added in fixed order
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[((long)(g + u) * NPART + part) * NE + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; g < GX; ++g) v += src[((long)g * NPART + part) * NE + e];
+        const int i = pair_row(F, q), j = pair_col(F, q);
+        out[i * F + j] = v;
+        out[j * F + i] = v;
+    }
+}
+
+inline bool gram_split_enabled() {
+    const char* e = getenv("SYMODE_GRAM_SPLIT");      // A-B knob: 0 keeps the MFMA form for 12 < F <= 24
+    return !(e && e[0] == '0');
+}
+
 inline bool gram_valu_gather_enabled() {
     const char* e = getenv("SYMODE_GRAM_VALU_GATHER");
     return e && e[0] == '1';
@@ -183,6 +344,21 @@ hipError_t launch_aug_gram_any(const float* x, const float* dx, long S, long n, 
             aug_gram_valu_kernel<Lib><<<dim3(gx_valu, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, vec, idx, part);
             SYMODE_LAUNCH_CHECK();
             gram_valu_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(part, gx_valu, gram);
+            SYMODE_LAUNCH_CHECK();
+            return hipSuccess;
+        }
+    }
+    if constexpr (GramSplitShape<Lib>::OK) {
+        if (gram_valu_enabled() && gram_split_enabled() && idx == nullptr) {
+            double* part = ws + WS_HEADER_DOUBLES;
+            const bool vec = vec_ok(x, n, Lib::D, S) && vec_ok(dx, n, Lib::D, S);
+            // one problem: 128 columns x NPART runs = one resident round of the chip (2 workgroups per CU at 193 VGPRs):
+            // 16 M points, order 5: 268 us against 334 us on 1024 columns (r02_gram_split.txt)
+            int GX = (gx_valu + 7) / 8 * 8;
+            if (S == 1 && GX > 128 && !getenv("SYMODE_GRAM_VALU_GRID")) GX = 128;
+            aug_gram_split_kernel<Lib><<<dim3(GX * GramSplitShape<Lib>::NPART, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, vec, GX, part);
+            SYMODE_LAUNCH_CHECK();
+            gram_split_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(part, GX, gram);
             SYMODE_LAUNCH_CHECK();
             return hipSuccess;
         }
