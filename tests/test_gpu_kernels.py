@@ -599,10 +599,12 @@ def test_weak_gram_fused_contraction(eng, T, K, d, order, fl):
 
 
 @pytest.mark.parametrize("S,n,d,order,fl", [(1, 125000, 2, 3, 0), (5, 4099, 2, 2, 2), (3, 1000, 2, 2, 0), (2, 777, 1, 5, 2), (1, 3000, 3, 1, 0),
-                                            (2, 5000, 2, 5, 0)])
+                                            (2, 5000, 2, 5, 0), (2, 3001, 2, 4, 0), (1, 2050, 2, 4, 3), (3, 999, 3, 2, 0),
+                                            (2, 1500, 4, 2, 0), (1, 70001, 3, 3, 0), (1, 8, 2, 5, 0)])
 def test_gram_vector_pipe_and_matrix_core_forms_agree(eng, S, n, d, order, fl):
-    """Small libraries (F = p + d <= 12) take the fp64 vector-pipe Gram (one fma per distinct entry), larger ones and
-    SYMODE_GRAM_VALU=0 the fp64 MFMA form: both are fp64 sums of exact products -- equal to 1e-12, and to the host's."""
+    """Small libraries (F = p + d <= 12) take the fp64 vector-pipe Gram (one fma per distinct entry), 12 < F <= 24 its split
+    form (the triangle in 2, 3 or 4 runs over sibling workgroups: F = 13, 17, 19, 21, 23 here), larger ones and
+    SYMODE_GRAM_VALU=0 the fp64 MFMA form: all are fp64 sums of exact products -- equal to 1e-12, and to the host's."""
     torch.manual_seed(n)
     x, dx = (torch.randn(S, n, d) * 0.7).cuda(), torch.randn(S, n, d).cuda()
     with _env(SYMODE_GRAM_VALU=1):
