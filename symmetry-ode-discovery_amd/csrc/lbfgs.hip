@@ -96,7 +96,7 @@ __device__ __forceinline__ float wave_amax(float v) {
 // test, x += t d.  act[s] goes in as "active" and comes out as "moved" (the closure has to be re-evaluated there).
 //
 // STAGED: the recursion is 2m dependent steps (dot product -> axpy), and read from global memory every step pays a
-// full memory round trip (~1.5 us x 100 steps at m = 50: the launch was 10x the closure kernel it sits beside).  The
+// full memory round trip (measured 42 us per launch at 64 problems, m <= 100, beside a 12 us closure kernel; 19 us now).  The
 // m pairs are therefore staged ONCE, all loads in flight together, into LDS in logical order ([k][i], k = 0 oldest) --
 // the pair made in this launch straight from registers -- and the loops run out of LDS.  Needs (2 n + 1) H floats
 // (<= 60 KB: n = 42, H = 100 is 34 KB); larger problems take the unstaged form (NC = 0).
