@@ -5,7 +5,7 @@ import symode_amd
 from symode_amd import data
 from symode_amd.batched import BatchedClosure
 from symode_amd.sweep import SeedSweepLBFGS
-S, n_ics, steps, order = 64, 50, 1000, 3
+S, n_ics, steps, order = int(os.environ.get("PS", "64")), 50, int(os.environ.get("PSTEPS", "1000")), 3
 X, DX = data.make_dataset("dosc", n_ics, steps, dt=0.02, noise=0.0, seed=10, device="cuda", n_problems=S)
 p = symode_amd.library.term_count(2, order)
 torch.manual_seed(0)
