@@ -322,9 +322,12 @@ inline bool gram_split_enabled() {
     return !(e && e[0] == '0');
 }
 
+// Index-table launches (seed sweeps over sorted subsamples): the vector-pipe form prefetches the next point's rows and,
+// since the launch geometry gives every thread >= 32 points, beats the MFMA form here too (r02_gather_gram.txt: 64 x 500 000
+// of 1 M rows 259 vs 410 us; 256 x 200 000 of 2 M rows 423 vs 634 us).  SYMODE_GRAM_VALU_GATHER=0 keeps the MFMA form.
 inline bool gram_valu_gather_enabled() {
     const char* e = getenv("SYMODE_GRAM_VALU_GATHER");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
 }
 
 inline bool gram_valu_enabled() {
@@ -335,8 +338,7 @@ inline bool gram_valu_enabled() {
 template <class Lib>
 hipError_t launch_aug_gram_any(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
                                int gx_mfma, int gx_valu, hipStream_t st) {
-    // index-table launches (random 8-byte rows) need more waves in flight than the register-bound vector form has:
-    // they keep the MFMA form, whose thread-per-point feature build runs at 4+ waves per SIMD
+    // (index-table launches of the 12 < F <= 24 libraries keep the MFMA form: the split kernel has no gather path)
     if constexpr (GramValuShape<Lib>::OK) {
         if (gram_valu_enabled() && (idx == nullptr || gram_valu_gather_enabled())) {
             double* part = ws + WS_HEADER_DOUBLES;

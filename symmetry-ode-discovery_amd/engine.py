@@ -272,7 +272,8 @@ class HipEngine:
             raise SymodeError("aug_gram_gather expects x, dx (N, d) and idx (S, M)")
         n_src, d = x.shape
         S, m = idx.shape
-        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_src):       # the kernel trusts the table
+        lo, hi = torch.stack(torch.aminmax(idx)).tolist() if idx.numel() else (0, 0)   # one reduction, one sync
+        if lo < 0 or hi >= max(n_src, 1):                                               # the kernel trusts the table
             raise SymodeError("idx holds row indices outside [0, N)")
         p = self.lib_size(d, order, flags)
         gram = torch.empty(S, p + d, p + d, dtype=torch.float64, device=x.device)
