@@ -291,7 +291,9 @@ def test_fused_lbfgs_iteration_matches_the_tensor_op_form_and_torch(S, monkeypat
     (n = 150), problems that stop early (one starts at its optimum, one has a zero gradient direction)."""
     from symode_amd.sweep import BatchedLBFGS
     eng = S.get_engine()
-    for n, H, Sn, lr, steps in [(7, 100, 6, 0.3, 4), (20, 4, 9, 0.2, 3), (150, 100, 5, 0.05, 2)]:
+    # (n, history): components per lane 1 (n <= 64), 2, 3, 4 of the LDS-staged recursion, and the unstaged form (150, 100)
+    for n, H, Sn, lr, steps in [(7, 100, 6, 0.3, 4), (20, 4, 9, 0.2, 3), (150, 100, 5, 0.05, 2), (100, 20, 4, 0.05, 2),
+                                (150, 8, 3, 0.05, 2), (256, 6, 3, 0.03, 2)]:
         torch.manual_seed(n)
         A = torch.randn(Sn, n, n) / n ** 0.5
         A = A @ A.transpose(1, 2) + 0.5 * torch.eye(n)
