@@ -22,6 +22,7 @@ Prints ONE JSON line (rank 0) following the driver's contract, plus
   cpu_baseline  : the CPU oracle ("port" of the reference op sequence) timed on the host cores on a bounded sample of
                   the same step (rank 0, N = 1 only),
   single_problem: the bare 50x2500x2 shape, kernel time and closure wall time.
+  seed_sweeps: wall time of the 64-seed L-BFGS and sequential-threshold sweeps at BASELINE config[3]'s size (informational).
 """
 import argparse
 import json
@@ -55,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernels (default: 1 on one GPU, 2 when the [loss|grad] buffer is all-reduced)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
+    ap.add_argument("--no_sweeps", action="store_true", help="skip the informational seed-sweep timings (N = 1 only)")
     ap.add_argument("--shard", choices=["points", "seeds"], default="points",
                     help="N > 1: 'points' = every rank holds a shard of each problem's trajectories and the packed "
                          "[loss|grad] partials are all-reduced (RCCL, default); 'seeds' = every rank owns whole problems, "
@@ -192,6 +194,48 @@ def _pmc_traffic(kernel_key, points_per_launch):
         except Exception:
             pass
     return None
+
+
+def seed_sweeps(eng, dev):
+    """Informational (not part of ``value``): wall time of the two seed-sweep drivers at BASELINE config[3]'s size --
+    64 seeds x 50 000 points, order 3 -- best of 3: the L-BFGS sweep (closure kernel + ONE optimiser launch per inner
+    iteration) and the sequential-threshold sweep (device subsample draw, index-table Gram, host solves)."""
+    import torch
+    out = {"shape": "64 seeds x 50000 points x 2, order 3"}
+    try:
+        from symode_amd import data
+        from symode_amd.batched import BatchedClosure
+        from symode_amd.sweep import SeedSweepLBFGS, SeedSweepSTLSQ
+        X, DX = data.make_dataset("dosc", 50, 1000, dt=0.02, noise=0.0, seed=10, device=dev, n_problems=64)
+        torch.manual_seed(0)
+        inits = torch.randn(64, 20, device=dev)
+        sw = SeedSweepLBFGS(BatchedClosure(X, DX, 3, engine=eng), 0.1, 0.05, 50)
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fit = sw.fit(inits, 60)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["lbfgs_sweep_ms"] = best * 1e3
+        out["lbfgs_sweep_epochs_max"] = int(fit["epochs"].max())
+        out["lbfgs_optimiser_launches_per_iteration"] = 1
+        xs, dxs = X[0].reshape(-1, 2).contiguous(), DX[0].reshape(-1, 2).contiguous()
+        xs, dxs = xs.repeat(2, 1)[:100000].contiguous(), dxs.repeat(2, 1)[:100000].contiguous()
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = SeedSweepSTLSQ(xs, dxs, 3, n_seeds=64, subsample=0.5, seed0=0, engine=eng)
+            _, _, passes = st.solve(0.0, 0.05, max_iter=10)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["stlsq_sweep_ms"] = best * 1e3
+        out["stlsq_passes"] = int(passes.sum())
+    except Exception as e:                                   # never let an informational leg fail the bench line
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def main():
@@ -398,6 +442,8 @@ def main():
     }
     if single:
         res["single_problem"] = single
+    if world == 1 and not a.profile and not a.no_sweeps:
+        res["seed_sweeps"] = seed_sweeps(eng, dev)
     if world == 1 and not a.no_cpu_baseline and not a.profile:
         ns = min(S, 4)
         Xi_s = clos.xi_from(beta, const)[:ns].cpu()
