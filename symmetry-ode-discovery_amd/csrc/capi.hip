@@ -67,7 +67,8 @@ inline int gram_valu_grid(long n, long S, int d) {
     // at least 32 points per thread: the epilogue transposes 78 fp64 sums per thread through LDS (ten rounds), which a
     // thread must amortise over its own 78-fma-per-point work; beyond that, enough workgroups to fill the chip
     long g = (n + 256L * 32 - 1) / (256L * 32);
-    const long want = (total + S - 1) / S;                 // ~`total` workgroups in all
+    long want = (total + S - 1) / S;                       // ~`total` workgroups in all
+    if (S == 1 && want > 512 && !getenv("SYMODE_GRAM_VALU_GRID")) want = 512;   // one problem: 16 M points 84 vs 97 us, 64 M equal
     if (g > want) g = want;
     if (g < 1) g = 1;
     return (int)g;

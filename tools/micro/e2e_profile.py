@@ -11,7 +11,7 @@ extra = sys.argv[2:]
 work = tempfile.mkdtemp(prefix="e2e_")
 shutil.copytree(os.path.join(os.path.dirname(os.path.abspath(M.__file__)), "run_configs"), os.path.join(work, "run_configs"))
 os.chdir(work)
-argv = ["--seed", "0", "--config", cfg, "--gpu", "0"] + extra
+argv = ["--seed", "0", "--config", cfg, "--gpu", "0"] + extra        # (main_sweep: pass --n_seeds / --method among the extras)
 if os.environ.get("E2E_PREP"):                      # e.g. E2E_PREP="lv/noise99_sym.cfg --num_epochs 1": a run whose outputs cfg loads
     prep = os.environ["E2E_PREP"].split()
     t0 = time.perf_counter()
