@@ -27,15 +27,21 @@ __device__ __forceinline__ float dpp_take(float old, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, false));
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_full(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ float wave_sum_dpp(float v) {
     const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(h[0]) + __uint_as_float(h[1]);
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    v += dpp_take<0x128, 0xf>(v, v);                                  // row_ror:8
+    // (full-mask permutes are written with old = 0 / bound_ctrl so that the compiler folds them into ONE v_add_f32_dpp)
+    v += dpp_full<0x128>(v);                                          // row_ror:8
     v += dpp_take<0x114, 0xa>(dpp_take<0x104, 0x5>(v, v), v);         // row_shl:4 -> quads 0, 2; row_shr:4 -> quads 1, 3
-    v += dpp_take<0x4E, 0xf>(v, v);                                   // quad_perm:[2,3,0,1]
-    v += dpp_take<0xB1, 0xf>(v, v);                                   // quad_perm:[1,0,3,2]
+    v += dpp_full<0x4E>(v);                                           // quad_perm:[2,3,0,1]
+    v += dpp_full<0xB1>(v);                                           // quad_perm:[1,0,3,2]
     return v;
 }
 
