@@ -129,13 +129,13 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
                                                             float tol_change, AcceptArgs acc) {
     constexpr bool STAGED = NC > 0;
     __shared__ float al[LB_MAXH];
-    extern __shared__ float staged[];                        // STAGED: Y [H][n] | S [H][n] | ro [H] | 256 floats of padding
+    extern __shared__ float staged[];                        // STAGED: pad [n] | Y [H][n] | S [H][n] | ro [H] | 256 floats of padding
     const long s = blockIdx.x;
     const int lane = threadIdx.x;
     if (!__builtin_amdgcn_readfirstlane((int)act[s])) return;   // wave-uniform: this problem stopped earlier
-    float* const ldsY = staged;
-    float* const ldsS = staged + H * n;
-    float* const ldsR = staged + 2 * H * n;
+    float* const ldsY = staged + n;                          // (a row of padding in front: the loops prefetch row -1)
+    float* const ldsS = ldsY + H * n;
+    float* const ldsR = ldsS + H * n;
     float gv[LB_MAXC], q[LB_MAXC];
     float loss_s;
     if constexpr (ACCEPT) {
@@ -255,18 +255,26 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < NC; ++c) on[c] = lane + WAVE * c < n;
         float sc[NC], yc[NC], sn[NC], yn[NC], rc, rn, al0 = 0.0f, al1 = 0.0f;
-        auto fetch = [&](int k, float (&sr)[NC], float (&yr)[NC], float& rr) {
+        // rows are walked with stepped pointers (one add per array and step; indexing by k costs a v_mul_lo per step on a
+        // lone wave that issues one instruction per 4 cycles); the prefetch of the row past the end reads padding
+        auto fetch = [&](const float* sp_, const float* yp_, const float* rp_, float (&sr)[NC], float (&yr)[NC], float& rr) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float sv_ = ldsS[k * n + lane + WAVE * c], yv_ = ldsY[k * n + lane + WAVE * c];
+                const float sv_ = sp_[WAVE * c], yv_ = yp_[WAVE * c];
                 sr[c] = on[c] ? sv_ : 0.0f;
                 yr[c] = on[c] ? yv_ : 0.0f;
             }
-            rr = ldsR[k];
+            rr = *rp_;
         };
-        if (m > 0) fetch(m - 1, sc, yc, rc);
+        const float* sp = ldsS + (m - 1) * n + lane;
+        const float* yp = ldsY + (m - 1) * n + lane;
+        const float* rp = ldsR + (m - 1);
+        if (m > 0) fetch(sp, yp, rp, sc, yc, rc);
         for (int k = m - 1; k >= 0; --k) {                   // newest -> oldest
-            fetch(k > 0 ? k - 1 : 0, sn, yn, rn);
+            sp -= n;
+            yp -= n;
+            rp -= 1;
+            fetch(sp, yp, rp, sn, yn, rn);                   // row k - 1 (row -1: the padding, never used)
             float part = 0.0f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) part = fmaf(sc[c], q[c], part);
@@ -283,9 +291,15 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) q[c] *= hd;
-        if (m > 0) fetch(0, sc, yc, rc);
+        sp = ldsS + lane;
+        yp = ldsY + lane;
+        rp = ldsR;
+        if (m > 0) fetch(sp, yp, rp, sc, yc, rc);
         for (int k = 0; k < m; ++k) {                        // oldest -> newest
-            fetch(k + 1 < m ? k + 1 : k, sn, yn, rn);
+            sp += n;
+            yp += n;
+            rp += 1;
+            fetch(sp, yp, rp, sn, yn, rn);                   // row k + 1 (row m: stale or padding, never used)
             float part = 0.0f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) part = fmaf(yc[c], q[c], part);
@@ -456,7 +470,7 @@ inline int launch_lbfgs_update(bool accept, float* params, float* g, float* loss
     if (!params || !g || !loss || !act || !n_iter || !d || !t || !old_dirs || !old_stps || !ro || !head || !count || !h_diag ||
         !prev_g || !prev_loss || (accept && (!acc.new_loss || !acc.new_g)))
         return SYMODE_E_NULLPTR;
-    const size_t stage_bytes = (((size_t)2 * n + 1) * history + 256) * sizeof(float);
+    const size_t stage_bytes = (((size_t)2 * n + 1) * history + n + 256) * sizeof(float);
     const int nc = stage_bytes <= 60 * 1024 ? (n + WAVE - 1) / WAVE : 0;
 #define SYMODE_LBFGS_UPDATE(NC_, BYTES_)                                                                                          \
     do {                                                                                                                          \
