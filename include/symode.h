@@ -245,6 +245,17 @@ int symode_lbfgs_accept(const float* new_loss, const float* new_g, float* loss, 
 int symode_host_lstsq_normal(const double* G, const double* C, int n, int k, long m_rows, int driver, double rcond,
                              double* W, int* rank_out);
 
+/* HOST function (no GPU work): sequential-threshold least squares to convergence for S problems from their augmented Gram
+ * matrices G (S, p+d, p+d) fp64 (symode_aug_gram / _gather output copied to the host); n_points rows each, ridge weight
+ * gamma, strict > threshold on fp32-rounded coefficients, at most max_iter passes, driver as symode_host_lstsq_normal.
+ * xi_out (S, d, p) fp32, mask_out (S, d, p) bytes, passes_out (S); near_out (S, may be NULL): coefficients met within
+ * near_band of the threshold; fallback_out (S, may be NULL): singular systems handed to the
+ * rank-revealing solve.
+ * replaces: the per-seed loop of train.py:872-887 over solve_SINDy_one_step (sindy.py:250-315), unconstrained case. */
+int symode_host_stlsq_sweep(const double* G, int S, int d, int p, long n_points, double gamma, double threshold, int max_iter,
+                            int driver, double near_band, float* xi_out, unsigned char* mask_out, int* passes_out,
+                            int* near_out, int* fallback_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,3 +201,87 @@ extern "C" int symode_host_lstsq_normal(const double* G, const double* C, int n,
         for (int col = 0; col < k; ++col) W[(size_t)piv[i] * k + col] = Y[(size_t)i * k + col];
     return SYMODE_OK;
 }
+
+
+// Sequential-threshold least squares to convergence for S problems from their augmented Gram matrices -- the loop of
+// train.py:872-887 around solve_SINDy_one_step (sindy.py:250-315), unconstrained case, as sweep.SeedSweepSTLSQ.solve
+// states it in numpy: per pass the ridge system on the current support (full mask: one (p, p) system with d right-hand
+// sides; otherwise the reference's block-diagonal, column-selected system in equation-major order, solved as ONE system
+// because gelsy's rank decision is joint), coefficients rounded to fp32, strict > threshold on the still-active
+// entries, until the mask repeats.  gels meeting a singular system falls back to the rank-revealing solve at fp64 working
+// accuracy (lstsq.py::_singular_fallback) and counts it.  Same solver, same inputs, same arithmetic as the Python loop:
+// 24 us -> ~3 us per pass.
+extern "C" int symode_host_stlsq_sweep(const double* G, int S, int d, int p, long n_points, double gamma, double threshold,
+                                       int max_iter, int driver, double near_band, float* xi_out, unsigned char* mask_out,
+                                       int* passes_out, int* near_out, int* fallback_out) {
+    if (S < 0 || d < 1 || p < 1 || max_iter < 1 || (driver != 0 && driver != 1)) return SYMODE_E_BADSIZE;
+    if (S == 0) return SYMODE_OK;
+    if (!G || !xi_out || !mask_out || !passes_out) return SYMODE_E_NULLPTR;
+    const int F = p + d, dp = d * p;
+    const float thr32 = (float)threshold;
+    std::vector<double> Gtt((size_t)p * p), Gty((size_t)p * d), W, Gm, cm, w;
+    std::vector<int> sel;
+    auto solve = [&](const double* A, const double* C, int n, int k, long m_rows, double* out, int& fell) -> int {
+        int rank = 0;
+        int rc = symode_host_lstsq_normal(A, C, n, k, m_rows, driver, -1.0, out, &rank);
+        if (rc != SYMODE_OK && driver == 1) {                      // singular under the full-rank driver
+            ++fell;
+            rc = symode_host_lstsq_normal(A, C, n, k, m_rows, 0, 1e-7, out, &rank);
+        }
+        return rc;
+    };
+    for (int s = 0; s < S; ++s) {
+        const double* Gs = G + (size_t)s * F * F;
+        for (int i = 0; i < p; ++i) {
+            for (int j = 0; j < p; ++j) Gtt[(size_t)i * p + j] = Gs[(size_t)i * F + j] + (i == j ? gamma * gamma : 0.0);
+            for (int j = 0; j < d; ++j) Gty[(size_t)i * d + j] = Gs[(size_t)i * F + p + j];
+        }
+        unsigned char* mask = mask_out + (size_t)s * dp;
+        float* xi32 = xi_out + (size_t)s * dp;
+        for (int f = 0; f < dp; ++f) mask[f] = 1;
+        int near = 0, fell = 0, passes = 0;
+        for (int it = 0; it < max_iter; ++it) {
+            std::vector<double> xi((size_t)dp, 0.0);
+            sel.clear();
+            for (int f = 0; f < dp; ++f)
+                if (mask[f]) sel.push_back(f);
+            const int nnz = (int)sel.size();
+            if (nnz == dp) {
+                W.assign((size_t)p * d, 0.0);
+                const int rc = solve(Gtt.data(), Gty.data(), p, d, n_points + p, W.data(), fell);
+                if (rc != SYMODE_OK) return rc;
+                for (int j = 0; j < d; ++j)
+                    for (int k = 0; k < p; ++k) xi[(size_t)j * p + k] = W[(size_t)k * d + j];
+            } else if (nnz > 0) {
+                Gm.assign((size_t)nnz * nnz, 0.0);
+                cm.assign((size_t)nnz, 0.0);
+                w.assign((size_t)nnz, 0.0);
+                for (int a = 0; a < nnz; ++a) {
+                    const int ja = sel[a] / p, ka = sel[a] % p;
+                    cm[a] = Gty[(size_t)ka * d + ja];
+                    for (int b = 0; b < nnz; ++b)
+                        if (sel[b] / p == ja) Gm[(size_t)a * nnz + b] = Gtt[(size_t)ka * p + sel[b] % p];
+                }
+                const int rc = solve(Gm.data(), cm.data(), nnz, 1, (long)d * (n_points + p), w.data(), fell);
+                if (rc != SYMODE_OK) return rc;
+                for (int a = 0; a < nnz; ++a) xi[sel[a]] = w[a];
+            }
+            bool converged = true;
+            for (int f = 0; f < dp; ++f) {
+                const float v = (float)xi[f];
+                xi32[f] = v;
+                const float av = std::fabs(v);
+                if (mask[f] && std::fabs((double)av - threshold) < near_band) ++near;
+                const unsigned char nm = (mask[f] && av > thr32) ? 1 : 0;
+                if (nm != mask[f]) converged = false;
+                mask[f] = nm;
+            }
+            passes = it + 1;
+            if (converged) break;
+        }
+        passes_out[s] = passes;
+        if (near_out) near_out[s] = near;
+        if (fallback_out) fallback_out[s] = fell;
+    }
+    return SYMODE_OK;
+}

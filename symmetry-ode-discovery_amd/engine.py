@@ -67,6 +67,8 @@ _SIGNATURES = {
     "symode_lbfgs_accept_update": (c_int, [c_void_p, c_void_p, c_float, c_int, c_float, c_float] + [c_void_p] * 15
                                    + [c_long, c_int, c_int, c_float, c_float, c_void_p]),
     "symode_lbfgs_accept": (c_int, [c_void_p] * 8 + [c_long, c_int, c_float, c_float, c_void_p, c_float, c_float, c_void_p]),
+    "symode_host_stlsq_sweep": (c_int, [c_void_p, c_int, c_int, c_int, c_long, ctypes.c_double, ctypes.c_double, c_int, c_int,
+                                        ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
 

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from .engine import get_engine, library_flags
+from . import lstsq as _lstsq
 from .sindy import NEAR_THRESHOLD_BAND, near_threshold_cases, stlsq_solve_from_gram
 
 
@@ -85,7 +86,28 @@ class SeedSweepSTLSQ:
         mask = np.ones((S, d, p), dtype=bool)
         passes = np.zeros(S, dtype=np.int64)
         self.near_threshold = []              # (seed index, pass, row, col, |coef|): BASELINE.md section 3
-        for s in range(S):
+        todo = range(S)
+        lib = _lstsq._native() if os.environ.get('SYMODE_STLSQ_NATIVE', '1') != '0' else None
+        if lib and lstsq_driver in ('gels', 'gelsy'):
+            # the whole loop below for all seeds in ONE native call (host_lstsq.cpp::symode_host_stlsq_sweep: same solver, same
+            # inputs, same arithmetic); seeds that met a near-threshold coefficient are replayed here for the detailed record
+            Gc = np.ascontiguousarray(G, dtype=np.float64)
+            m8 = np.ones((S, d, p), dtype=np.uint8)
+            p32, near, fell = np.zeros(S, dtype=np.int32), np.zeros(S, dtype=np.int32), np.zeros(S, dtype=np.int32)
+            rc = lib.symode_host_stlsq_sweep(Gc.ctypes.data, S, d, p, int(self.n_points), float(w_sindy_reg), float(threshold),
+                                             int(max_iter), 0 if lstsq_driver == 'gelsy' else 1, float(NEAR_THRESHOLD_BAND),
+                                             Xi.ctypes.data, m8.ctypes.data, p32.ctypes.data, near.ctypes.data, fell.ctypes.data)
+            if rc != 0:
+                raise RuntimeError(f'symode_host_stlsq_sweep failed with code {rc}')
+            if fell.any():
+                import warnings
+                warnings.warn('singular normal equations under the full-rank (gels) driver: minimum-norm solution returned instead',
+                              RuntimeWarning)
+            mask, passes = m8.astype(bool), p32.astype(np.int64)
+            todo = [int(s) for s in np.nonzero(near)[0]]
+            for s in todo:
+                mask[s] = True
+        for s in todo:
             for it in range(max_iter):
                 xi, _ = stlsq_solve_from_gram(G[s], self.n_points, mask[s], float(w_sindy_reg), d, lstsq_driver)
                 xi32 = xi.astype(np.float32)

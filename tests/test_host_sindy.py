@@ -228,6 +228,59 @@ def test_seed_sweep_matches_per_seed_stlsq(golden):
     assert len({tuple(sw.idx[s].tolist()) for s in range(5)}) == 5          # every seed has its own subsample
 
 
+def test_native_stlsq_sweep_equals_the_python_loop(monkeypatch):
+    """host_lstsq.cpp::symode_host_stlsq_sweep (every seed's sequential-threshold loop in one native call) vs the numpy
+    loop of SeedSweepSTLSQ.solve: bit-identical coefficients, masks and pass counts -- both drivers, with and without ridge,
+    supports that shrink over several passes (noisy data, thresholds inside the coefficient range), a seed whose support
+    empties, a singular system under gels (duplicated column -> rank-revealing fallback + warning), and the
+    near-threshold record of a seed that meets one."""
+    import warnings
+    from symode_amd.sweep import SeedSweepSTLSQ
+    rng = np.random.RandomState(7)
+    S, d, p, n = 9, 2, 10, 4000
+
+    def grams(noise, dup=False):
+        G = np.zeros((S, p + d, p + d))
+        for s in range(S):
+            A = rng.randn(n, p) * (0.3 + rng.rand(p))
+            A[:, 0] = 1.0
+            if dup and s == 2:
+                A[:, 7] = A[:, 3]                                         # exactly collinear pair: singular under gels
+            W = np.zeros((p, d))
+            W[1, 0], W[2, 0], W[1, 1], W[2, 1], W[5, 1] = -0.1, -1.0, 1.0, -0.1, 0.07 + 0.02 * s
+            Y = A @ W + noise * rng.randn(n, d)
+            M = np.concatenate([A.astype(np.float32), Y.astype(np.float32)], axis=1).astype(np.float64)
+            G[s] = M.T @ M
+        return G
+
+    for driver, gamma, thr, noise, dup in [("gels", 0.0, 0.05, 0.3, False), ("gelsy", 0.0, 0.05, 0.3, False), ("gels", 0.05, 0.09, 1.0, False),
+                                           ("gelsy", 0.1, 0.5, 0.5, False), ("gels", 0.0, 0.05, 0.3, True), ("gels", 0.0, 5.0, 0.3, False)]:
+        sw = SeedSweepSTLSQ(torch.zeros(8, d), torch.zeros(8, d), 3, n_seeds=S, subsample=0.5, seed0=0, engine=OracleEngine())
+        sw._gram, sw.n_points = grams(noise, dup), n
+        out = {}
+        for native in ("1", "0"):
+            monkeypatch.setenv("SYMODE_STLSQ_NATIVE", native)
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                Xi, mask, passes = sw.solve(gamma, thr, max_iter=10, lstsq_driver=driver)
+            out[native] = (Xi.numpy().copy(), mask.numpy().copy(), passes.copy(), list(sw.near_threshold), len(rec))
+        a, b = out["1"], out["0"]
+        assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)), (driver, gamma, thr)     # bit-identical fp32 coefficients
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (driver, gamma, thr)
+        assert a[3] == b[3]
+        if dup:
+            assert a[4] >= 1                                                    # the singular-system warning was raised
+        if thr == 5.0:
+            assert not a[1].any() and (a[2] == 2).all()                          # everything cut in pass 1, empty support repeats
+    # a coefficient within 1e-4 of the threshold is recorded with its seed, pass and position
+    G1 = grams(0.0)
+    sw = SeedSweepSTLSQ(torch.zeros(8, d), torch.zeros(8, d), 3, n_seeds=S, subsample=0.5, seed0=0, engine=OracleEngine())
+    sw._gram, sw.n_points = G1, n
+    monkeypatch.setenv("SYMODE_STLSQ_NATIVE", "1")
+    sw.solve(0.0, 0.07 + 0.02 * 3 + 2e-5, max_iter=10, lstsq_driver="gels")     # seed 3's W[5, 1] sits 2e-5 below the threshold
+    assert any(s_ == 3 and (i, k) == (1, 5) for s_, _, i, k, _ in sw.near_threshold), sw.near_threshold
+
+
 def test_native_host_solver_equals_numpy_specification(golden):
     """csrc/host_lstsq.cpp vs lstsq.lstsq_normal_py: full rank, rank-truncated, rank-deficient, multiple RHS."""
     rng = np.random.RandomState(1)
