@@ -54,7 +54,15 @@ def constraint_Q(L_list, d: int, order: int):
             C = torch.kron(L.inverse(), M.T) - torch.eye(M.shape[0] * L.shape[0])
         blocks.append(C)
     C_total = torch.cat(blocks, dim=0)
-    _, sigma, V = torch.svd(C_total)                 # same LAPACK route as the reference (sindy.py:100)
+    # same LAPACK route as the reference (sindy.py:100) -- on ONE thread: a threaded BLAS under gesdd rounds differently
+    # with the thread count, and every process of a run (the ranks of a sweep, a 1-rank rerun) must build the same Q to
+    # the last bit for its masks to be comparable (the matrix is at most a few hundred rows: microseconds either way)
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        _, sigma, V = torch.svd(C_total)
+    finally:
+        torch.set_num_threads(n_threads)
     r = 0
     for r in range(len(sigma)):                      # sindy.py:102-104
         if abs(sigma[-1 - r]) > 5e-3:

@@ -30,7 +30,7 @@ from .evaluation import aggregate_results, sindy_truth
 from .lie import LieGenerator
 from .parser_utils import get_args
 from .sindy import SINDyRegression
-from .sweep import SeedSweepLBFGS, SeedSweepSTLSQ, seeded_subsample
+from .sweep import SeedSweepLBFGS, SeedSweepSTLSQ, seeded_subsamples
 
 
 def _pop(argv, flag, default, cast):
@@ -110,7 +110,7 @@ def main(argv=None, engine=None, backend='nccl', one_gpu=False):
     if method == 'stlsq':
         if args['eq_constraint']:
             raise SystemExit('--method stlsq sweeps the unconstrained library (use --method lbfgs for EquivSINDy-c)')
-        idx = torch.stack([seeded_subsample(n_all, m, s, dev)[lo:hi] for s in seeds])
+        idx = seeded_subsamples(n_all, m, seeds, dev)[:, lo:hi]
         sw = SeedSweepSTLSQ(x_all, dx_all, args['poly_order'], args['include_sine'], args['include_exp'], n_seeds=n_seeds,
                             subsample=args['lbfgs_subsample'], seed0=args['seed'], group=group, engine=engine, idx=idx)
         Xi, mask, passes = sw.solve(args['w_sindy_reg'], args['threshold'], max_iter=max(1, args['num_epochs']),
@@ -132,14 +132,14 @@ def main(argv=None, engine=None, backend='nccl', one_gpu=False):
         args['L_list'] = [L[:rd, :rd].detach().cpu() for L in L_list]
     template = SINDyRegression(**args, **({'engine': engine} if engine is not None else {})).to(dev)
     inits, xs, dxs = [], [], []
-    for s, g in zip(seeds, gens):
+    all_rows = seeded_subsamples(n_all, m, seeds, dev)[:, lo:hi]
+    for (s, g), rows in zip(zip(seeds, gens), all_rows):
         if template.constraint:
             beta = torch.randn(template.Q.shape[1], generator=g)
             const = torch.randn(template.latent_dim, generator=g)
             inits.append(torch.cat([beta, const]))
         else:
             inits.append(torch.randn(template.latent_dim * template.get_term_num(), generator=g))
-        rows = seeded_subsample(n_all, m, s, dev)[lo:hi]
         xs.append(x_all[rows])
         dxs.append(dx_all[rows])
     X, DX = torch.stack(xs).contiguous(), torch.stack(dxs).contiguous()

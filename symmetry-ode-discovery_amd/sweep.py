@@ -21,16 +21,22 @@ from . import lstsq as _lstsq
 from .sindy import NEAR_THRESHOLD_BAND, near_threshold_cases, stlsq_solve_from_gram
 
 
-def seeded_subsample(n, m, seed, device):
-    """The first m entries of a permutation of range(n) from a generator seeded by ``seed`` alone -- a seed's subsample
-    (main.py:36-38: the first batch of a shuffled loader).  Drawn where the data lives: torch's CPU randperm costs 8-17 ms
-    at n = 1e5 (64 seeds: 0.5-1.1 s, 100x the Gram pass and the solves together), the device one 0.05 ms.  Every rank of
-    a run draws the same permutation and takes its slice, so the union over ranks does not depend on the world size."""
+def seeded_subsamples(n, m, seeds, device):
+    """(len(seeds), m) int64, rows ascending: for every seed the m-subset of range(n) that holds the m smallest of n uniform
+    keys drawn from a generator seeded by THAT seed alone -- a seed's subsample (main.py:36-38: the first batch of a
+    shuffled loader) does not depend on which other seeds run beside it, nor on the world size (every rank draws the same
+    rows and takes its slice).  One key kernel per seed, ONE batched selection + sort for all of them: 1.1 ms for 64 seeds
+    of 10^5 rows, against 5 ms for a device randperm per seed and 0.5-1.1 s for torch's CPU randperm."""
     device = torch.device(device)
-    if device.type == 'cuda':
-        g = torch.Generator(device=device).manual_seed(int(seed))
-        return torch.randperm(n, generator=g, device=device)[:m]
-    return torch.randperm(n, generator=torch.Generator().manual_seed(int(seed)))[:m]
+    g = torch.Generator(device=device)
+    keys = torch.empty(len(seeds), n, dtype=torch.float64, device=device)          # fp64 keys: ties are not a concern
+    for row, seed in zip(keys, seeds):
+        g.manual_seed(int(seed))
+        row.uniform_(generator=g)
+    if m >= n:
+        return torch.arange(n, device=device).expand(len(seeds), n).contiguous()
+    idx = torch.topk(keys, m, dim=1, largest=False, sorted=False).indices
+    return torch.sort(idx, dim=1).values
 
 
 class SeedSweepSTLSQ:
@@ -57,10 +63,9 @@ class SeedSweepSTLSQ:
         else:
             rank = dist.get_rank(group) if group is not None else 0
             m = max(1, int(self.n_local * subsample))
-            rows = []
-            for s in range(n_seeds):                      # seeded permutation per (seed, rank): reproducible subsets
-                rows.append(seeded_subsample(self.n_local, m, 1_000_003 * (seed0 + s) + rank, x.device))
-            self.idx = torch.sort(torch.stack(rows), dim=1).values.to(torch.int32).to(x.device)
+            # seeded subset per (seed, rank): reproducible
+            self.idx = seeded_subsamples(self.n_local, m, [1_000_003 * (seed0 + s) + rank for s in range(n_seeds)],
+                                         x.device).to(torch.int32)
             self.m_local = m
         self._gram = None
 
