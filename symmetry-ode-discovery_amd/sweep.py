@@ -399,8 +399,10 @@ class SeedSweepLBFGS:
         return (A[:, :r] - B[:, :r]).norm(dim=1) + (A[:, r:] - B[:, r:]).norm(dim=1)
 
     @torch.no_grad()
-    def fit(self, P0, num_epochs, mask0=None):
+    def fit(self, P0, num_epochs, mask0=None, on_epoch=None):
         """P0 (S, n): initial flat parameters per seed ([Xi] or [beta | const]).
+        ``on_epoch(epoch, P, mask, done)`` (optional) is called after the epoch's logic with the live device tensors (a
+        caller that reads them synchronises; returning True ends the fit) -- per-epoch logs / interval checkpoints.
         Returns dict(Xi, mask, params, epochs (S,), finished (S,), nan (S,))."""
         c = self.c
         P = P0.clone().contiguous()
@@ -446,5 +448,7 @@ class SeedSweepLBFGS:
             n_iters = torch.where(ev, torch.zeros_like(n_iters), n_iters)
             pprev = torch.where(thr_conv[:, None], P, pprev)               # only on convergence-triggered events (:718)
             prev = torch.where((live & ~final)[:, None], P, prev)
+            if on_epoch is not None and on_epoch(epoch, P, self.mask, done):
+                break
         return {"Xi": self._xi(P), "mask": self.mask, "params": P, "epochs": epochs, "finished": done & ~nan, "nan": nan,
                 "near_threshold": near}

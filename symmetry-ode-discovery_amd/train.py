@@ -654,13 +654,14 @@ def _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, thre
 
 
 def _train_on_device(regressor, x, dx, autoencoder, generator, num_epochs, lr_sindy, st_freq, threshold, w_sindy_x,
-                     sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq):
+                     sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq, log_interval=0, save_interval=0):
     """The non-latent L-BFGS fit with NOTHING on the host between epochs: the one-seed case of sweep.SeedSweepLBFGS --
     closure kernel + one optimiser launch per inner iteration (symode_lbfgs_accept_update), the per-epoch logic of
     train.py:692-725 (NaN guard, update-norm test, thresholding, optimiser reset, final convergence) as mask arithmetic
     on device tensors, one host sync every fourth epoch.  Same update rules and events as the default path statement
-    by statement, but torch's own optimiser it is not: on the recorded runs it lands on the same masks (tests), the
-    per-epoch log lines / interval checkpoints of the default path are not produced (final state and its checkpoint are).
+    by statement, but torch's own optimiser it is not: on the recorded runs it lands on the same masks (tests).  Log lines
+    and interval checkpoints are produced at ``log_interval`` / ``save_interval`` (each one synchronises); the per-epoch
+    wandb record and the "test" log of the default path are not.
     7.6 ms against 48 ms for the 125 000-point problem (profiles/r02_sweep_lbfgs.txt)."""
     from .batched import BatchedClosure
     from .sweep import SeedSweepLBFGS
@@ -683,16 +684,37 @@ def _train_on_device(regressor, x, dx, autoencoder, generator, num_epochs, lr_si
             P0 = regressor.Xi.detach().reshape(1, -1)
     sweep = SeedSweepLBFGS(clos, lr_sindy, threshold, st_freq, w_sindy_x=w_sindy_x, sindy_reg_type=sindy_reg_type,
                            w_sindy_reg=w_sindy_reg)
-    out = sweep.fit(P0.float().contiguous(), num_epochs, mask0=regressor.mask[None].clone())
+    def adopt(P, mask):                                    # the sweep's state into the regressor (device copies)
+        with torch.no_grad():
+            if regressor.constraint:
+                r = regressor.Q.shape[1]
+                regressor.beta.data.copy_(P[:r].view_as(regressor.beta))
+                regressor.const.data.copy_(P[r:].view_as(regressor.const))
+            else:
+                regressor.Xi.data.copy_(P.view_as(regressor.Xi))
+            regressor.mask.data = mask.clone()
+
+    def on_epoch(epoch, P, mask, done):
+        log = log_interval > 0 and (epoch + 1) % log_interval == 0
+        save = save_interval > 0 and (epoch + 1) % save_interval == 0
+        if log or save:
+            adopt(P[0], mask[0])
+            if log:
+                with torch.no_grad():
+                    cur, _ = clos.loss_grad_xi(sweep._xi(P), mask)
+                key = 'loss_sindy_x' if rev is None else 'loss_sindy_x_plus_sym_reg'
+                print(f'Epoch {epoch}, {key}: {float(cur[0]):.4f}')
+                if print_eq:
+                    regressor.print()
+            if save:
+                _save(regressor, save_dir, f'regressor_{epoch}.pt')
+            return bool(done.all())                        # (already synchronised: stop right at the final epoch)
+        return False
+
+    out = sweep.fit(P0.float().contiguous(), num_epochs, mask0=regressor.mask[None].clone(),
+                    on_epoch=on_epoch if (log_interval > 0 or save_interval > 0) else None)
+    adopt(out['params'][0], out['mask'][0])
     with torch.no_grad():
-        P = out['params'][0]
-        if regressor.constraint:
-            r = regressor.Q.shape[1]
-            regressor.beta.data.copy_(P[:r].view_as(regressor.beta))
-            regressor.const.data.copy_(P[r:].view_as(regressor.const))
-        else:
-            regressor.Xi.data.copy_(P.view_as(regressor.Xi))
-        regressor.mask.data = out['mask'][0].clone()
         final, _ = clos.loss_grad_xi(out['Xi'], regressor.mask[None])          # mse, or mse + (w_sym / w_x) * regulariser
         losses['loss_sindy_x' if rev is None else 'loss_sindy_x_plus_sym_reg'] = final[0].clone()
     epochs = int(out['epochs'][0])
@@ -784,7 +806,7 @@ def train_SIGED_lbfgs(
     if eligible and kwargs.get('device_lbfgs', False) and w_sindy_x > 0 and sindy_reg_type in ('l1', 'none'):
         # opt-in (--device_lbfgs): optimiser AND per-epoch logic on the device -- see _train_on_device
         return _train_on_device(regressor, x, dx, autoencoder, generator, num_epochs, lr_sindy, st_freq, threshold, w_sindy_x,
-                                sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq)
+                                sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq, log_interval, save_interval)
     if eligible:
         rev = None
         if w_sym_reg > 0.0:

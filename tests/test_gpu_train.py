@@ -1,5 +1,7 @@
 """GPU parity of the training-loop layer: L-BFGS trainer, symmetry regularisers (S1-S4) and the
 integrator, through the HIP engine, against the reference's recorded outputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -185,6 +187,30 @@ def test_trainer_with_symmetry_regulariser_runs_and_matches_oracle_closure(S, go
     first, last = logged[0], logged[-1]
     assert last["loss_sindy_x"] < first["loss_sindy_x"] * 1.01
     assert "loss_sym_reg" in first and first["loss_sym_reg"] >= 0
+
+
+def test_device_lbfgs_path_writes_logs_and_interval_checkpoints(S, golden, tmp_path, monkeypatch, capsys):
+    """``device_lbfgs=True`` with the reference configs' log / save intervals: an 'Epoch k, loss_sindy_x' line per logged
+    epoch, ``regressor_<epoch>.pt`` at the save interval and at the end, and the same final mask as without them."""
+    monkeypatch.chdir(tmp_path)
+    g = golden("f4_lbfgs")
+    x, dx = t(g["dosc_sindy_x"]), t(g["dosc_sindy_dx"])
+    ident = torch.nn.Identity()
+    masks = []
+    for log, save in ((1, 2), (10 ** 9, 10 ** 9)):
+        r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV)
+        r.Xi.data = t(g["dosc_sindy_init_Xi"]).to(DEV)
+        S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ident, generator=ident, regressor=r,
+                                  **_train_kwargs(num_epochs=60, lr_sindy=0.1, threshold=0.05, st_freq=50, device_lbfgs=True,
+                                                  log_interval=log, save_interval=save, save_dir=f"dl{log}"))
+        masks.append(r.mask.cpu().numpy())
+    out = capsys.readouterr().out
+    assert "Epoch 0, loss_sindy_x:" in out and "Epoch 1, loss_sindy_x:" in out and "Final convergence reached" in out
+    files = sorted(os.listdir("saved_models/dl1"))
+    assert "regressor_1.pt" in files and "regressor_3.pt" in files and len(files) >= 3
+    state = torch.load(f"saved_models/dl1/{files[-1]}", weights_only=True)
+    assert set(state) == {"Xi"}
+    assert np.array_equal(masks[0], masks[1]) and np.array_equal(masks[0], g["dosc_sindy_mask_final"])
 
 
 def test_reversed_regulariser_host_and_device_lbfgs_agree(S, golden, tmp_path, monkeypatch):
