@@ -519,6 +519,125 @@ class _NoZeroGrad:
         pass
 
 
+class _PlainLBFGS:
+    """torch.optim.LBFGS (no line search) as the SAME sequence of torch tensor operations on the same parameter list --
+    hence bit-identical iterates (tests/test_host_train.py) -- without deriving from torch.optim.Optimizer: constructing
+    any torch optimiser imports torch._dynamo (0.55 s, a quarter of a one-seed process of the reference's run scripts).
+    ``SYMODE_TORCH_OPTIM=1`` puts torch's own class back."""
+
+    def __init__(self, params, lr=1.0, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100):
+        self.params = list(params)
+        self.lr, self.max_iter = lr, max_iter
+        self.max_eval = max_iter * 5 // 4 if max_eval is None else max_eval
+        self.tol_g, self.tol_c, self.H = tolerance_grad, tolerance_change, history_size
+        self.func_evals = self.n_iter = 0
+        self.d = self.t = self.old_dirs = self.old_stps = self.ro = self.H_diag = self.prev_flat_grad = self.prev_loss = None
+        self.al = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_().zero_()
+
+    def _flat_grad(self):
+        return torch.cat([p.new(p.numel()).zero_() if p.grad is None else p.grad.view(-1) for p in self.params], 0)
+
+    def _move(self, step_size, update):
+        offset = 0
+        for p in self.params:
+            numel = p.numel()
+            p.add_(update[offset:offset + numel].view_as(p), alpha=step_size)
+            offset += numel
+
+    @torch.no_grad()
+    def step(self, closure):
+        closure = torch.enable_grad()(closure)
+        orig_loss = closure()
+        loss = float(orig_loss)
+        current_evals = 1
+        self.func_evals += 1
+        flat_grad = self._flat_grad()
+        if flat_grad.abs().max() <= self.tol_g:
+            return orig_loss
+        d, t, old_dirs, old_stps, ro, H_diag = self.d, self.t, self.old_dirs, self.old_stps, self.ro, self.H_diag
+        prev_flat_grad, prev_loss = self.prev_flat_grad, self.prev_loss
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            self.n_iter += 1
+            if self.n_iter == 1:
+                d = flat_grad.neg()
+                old_dirs, old_stps, ro, H_diag = [], [], [], 1
+            else:
+                y = flat_grad.sub(prev_flat_grad)
+                s = d.mul(t)
+                ys = y.dot(s)
+                if ys > 1e-10:
+                    if len(old_dirs) == self.H:
+                        old_dirs.pop(0)
+                        old_stps.pop(0)
+                        ro.pop(0)
+                    old_dirs.append(y)
+                    old_stps.append(s)
+                    ro.append(1.0 / ys)
+                    H_diag = ys / y.dot(y)
+                num_old = len(old_dirs)
+                if self.al is None:
+                    self.al = [None] * self.H
+                al = self.al
+                q = flat_grad.neg()
+                for i in range(num_old - 1, -1, -1):
+                    al[i] = old_stps[i].dot(q) * ro[i]
+                    q.add_(old_dirs[i], alpha=-al[i])
+                d = r = torch.mul(q, H_diag)
+                for i in range(num_old):
+                    be_i = old_dirs[i].dot(r) * ro[i]
+                    r.add_(old_stps[i], alpha=al[i] - be_i)
+            if prev_flat_grad is None:
+                prev_flat_grad = flat_grad.clone(memory_format=torch.contiguous_format)
+            else:
+                prev_flat_grad.copy_(flat_grad)
+            prev_loss = loss
+            t = min(1.0, 1.0 / flat_grad.abs().sum()) * self.lr if self.n_iter == 1 else self.lr
+            gtd = flat_grad.dot(d)
+            if gtd > -self.tol_c:
+                break
+            ls_func_evals = 0
+            self._move(t, d)
+            if n_iter != self.max_iter:
+                with torch.enable_grad():
+                    loss = closure()
+                loss = float(loss)
+                flat_grad = self._flat_grad()
+                opt_cond = flat_grad.abs().max() <= self.tol_g
+                ls_func_evals = 1
+            current_evals += ls_func_evals
+            self.func_evals += ls_func_evals
+            if n_iter == self.max_iter:
+                break
+            if current_evals >= self.max_eval:
+                break
+            if opt_cond:
+                break
+            if d.mul(t).abs().max() <= self.tol_c:
+                break
+            if abs(loss - prev_loss) < self.tol_c:
+                break
+        self.d, self.t, self.old_dirs, self.old_stps, self.ro, self.H_diag = d, t, old_dirs, old_stps, ro, H_diag
+        self.prev_flat_grad, self.prev_loss = prev_flat_grad, prev_loss
+        return orig_loss
+
+
+def _new_lbfgs(params, lr):
+    """the L-BFGS of the trainers: torch's arithmetic without torch's Optimizer base (see _PlainLBFGS)"""
+    if os.environ.get('SYMODE_TORCH_OPTIM', '0') == '1':
+        return torch.optim.LBFGS(params, lr=lr)
+    return _PlainLBFGS(params, lr=lr)
+
+
 class _NumpyLBFGS:
     """torch.optim.LBFGS (no line search, default tolerances) on one flat float32 numpy vector.
 
@@ -605,7 +724,7 @@ def _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, thre
     fast = shadow is not None and shadow.flat is not None          # numpy variables + numpy L-BFGS
 
     def new_optimizer():
-        return _NumpyLBFGS(shadow.flat, lr_sindy) if fast else torch.optim.LBFGS(P.parameters(), lr=lr_sindy)
+        return _NumpyLBFGS(shadow.flat, lr_sindy) if fast else _new_lbfgs(P.parameters(), lr_sindy)
 
     optimizer = new_optimizer()
     prev_params = [p.detach().clone() for p in P.parameters()]

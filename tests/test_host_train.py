@@ -278,3 +278,47 @@ def test_symmetry_caches_see_parameter_and_offset_changes():
     assert abs(a - b) <= 1e-5 * abs(b)
     with pytest.raises(ValueError):
         MU.symmreg_f(x_fx, ae, gen, f, x_const=x + 1.0)
+
+
+def test_plain_lbfgs_is_bit_identical_to_torch_optim_lbfgs():
+    """train._PlainLBFGS (the trainers' default: torch.optim.LBFGS's tensor-op sequence without the Optimizer base and its
+    torch._dynamo import) against torch.optim.LBFGS itself: bit-equal parameters and returned losses after every step --
+    several parameter tensors, an ill-conditioned least-squares objective, a history that wraps (size 5), runs that stop
+    on the tolerances, a closure with an L1 term."""
+    from symode_amd.train import _PlainLBFGS
+    torch.manual_seed(3)
+    A = torch.randn(400, 12) * torch.logspace(0, -2.5, 12)
+    w_true = torch.randn(12, 2)
+    Y = A @ w_true + 0.01 * torch.randn(400, 2)
+    for lr, hist, l1, steps in [(1.0, 100, 0.0, 6), (0.3, 5, 0.0, 8), (0.1, 100, 0.05, 5), (1.0, 3, 0.0, 12)]:
+        runs = []
+        for cls in (torch.optim.LBFGS, _PlainLBFGS):
+            torch.manual_seed(11)
+            W = torch.randn(10, 2, requires_grad=True)
+            b = torch.randn(2, requires_grad=True)
+            c = torch.randn(2, 1, requires_grad=True)
+            opt = cls([W, b, c], lr=lr, history_size=hist)
+
+            def closure():
+                opt.zero_grad()
+                pred = A[:, :10] @ W + A[:, 10:] @ torch.stack([b, c[:, 0]])
+                loss = ((pred - Y) ** 2).mean() + l1 * (W.abs().sum() + b.abs().sum())
+                loss.backward()
+                return loss
+            trace = []
+            for _ in range(steps):
+                out = opt.step(closure)
+                trace.append((out.detach().clone(), W.detach().clone(), b.detach().clone(), c.detach().clone()))
+            runs.append(trace)
+        for (la, Wa, ba, ca), (lb, Wb, bb, cb) in zip(*runs):
+            assert torch.equal(la, lb) and torch.equal(Wa, Wb) and torch.equal(ba, bb) and torch.equal(ca, cb), (lr, hist, l1)
+    # a start at the optimum returns before the first move, like torch's
+    x = torch.zeros(3, requires_grad=True)
+    o = _PlainLBFGS([x], lr=1.0)
+
+    def at_optimum():
+        o.zero_grad()
+        l = (x ** 2).sum()
+        l.backward()
+        return l
+    assert float(o.step(at_optimum)) == 0.0 and o.n_iter == 0 and o.func_evals == 1
