@@ -201,6 +201,7 @@ class OracleRegressor:
         else:
             self.Xi = (torch.randn(latent_dim, p) if Xi0 is None else Xi0.clone().float()).requires_grad_(True)
         self.mask = torch.ones(latent_dim, p)                                # sindy.py:66
+        self.near_threshold = []                                             # see set_threshold
 
     # -- parameter plumbing --------------------------------------------------------
     def parameters(self):
@@ -220,7 +221,11 @@ class OracleRegressor:
 
     def set_threshold(self, thr):                                            # sindy.py:192-194
         with torch.no_grad():
-            self.mask = torch.logical_and(torch.abs(self.get_Xi()) > thr, self.mask).float()
+            a = torch.abs(self.get_Xi())
+            # live coefficients within 1e-4 of the threshold at a thresholding event, as (row, column)
+            self.near_threshold += [(int(i), int(k)) for i, k in
+                                    torch.nonzero(((a - thr).abs() < 1e-4) & (self.mask > 0)).tolist()]
+            self.mask = torch.logical_and(a > thr, self.mask).float()
 
     def reset_mask(self):                                                    # sindy.py:197-198
         self.mask = torch.ones_like(self.mask)

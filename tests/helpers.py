@@ -100,3 +100,44 @@ def load_fixture_generator(g, prefix, repr_str, device="cpu"):
     for p in gen.parameters():
         p.requires_grad = False
     return gen.to(device).eval()
+
+
+F11_GENERATORS = {"so2": [[0.0, 1.0], [-1.0, 0.0]], "scaling2": [[2.0, 0.0], [0.0, 1.0]]}
+
+
+def f11_case(g, tag):
+    """One record of tests/golden/f11_lbfgs_noisy.npz (the reference's train_SIGED_lbfgs on noisy, GP-smoothed data) as a dict."""
+    d, order, cc = [int(v) for v in g[f"{tag}_cfg"]]
+    lr, st_freq, thr, epochs = [float(v) for v in g[f"{tag}_hp"]]
+    c = dict(tag=tag, d=d, order=order, constrain_constant=bool(cc), lr=lr, st_freq=int(st_freq), thr=thr, epochs=int(epochs),
+             x=t(g[f"{tag}_x"]), dx=t(g[f"{tag}_dx"]), mask_final=g[f"{tag}_mask_final"], Xi_final=g[f"{tag}_Xi_final"],
+             loss_hist=g[f"{tag}_loss_hist"], thr_epoch=g[f"{tag}_thr_epoch"], thr_Xi=g[f"{tag}_thr_Xi"],
+             thr_mask_before=g[f"{tag}_thr_mask_before"], L=None)
+    if f"{tag}_L" in g.files:
+        c.update(L=t(g[f"{tag}_L"]), Q=t(g[f"{tag}_Q"]), beta0=t(g[f"{tag}_init_beta"]), const0=t(g[f"{tag}_init_const"]),
+                 use_kron=bool(g[f"{tag}_use_kron"]))
+    else:
+        c["Xi0"] = t(g[f"{tag}_init_Xi"])
+    # the reference's own near-threshold record: live coefficients within 1e-4 of the threshold at its thresholding events
+    near = []
+    for Xi, m in zip(c["thr_Xi"], c["thr_mask_before"]):
+        hit = (np.abs(np.abs(Xi) - np.float32(thr)) < 1e-4) & (m > 0)
+        near += [(int(i), int(k)) for i, k in zip(*np.nonzero(hit))]
+    c["near"] = near
+    return c
+
+
+def f11_oracle_regressor(O, c, cls=None, own_Q=False):
+    """Oracle regressor at the recorded start of an f11 case (``own_Q``: keep the oracle's own null-space basis instead of the
+    reference's -- beta is then re-expressed in it, the start Xi is the same)."""
+    cls = cls or O.OracleRegressor
+    if c["L"] is None:
+        return cls(c["d"], c["order"], threshold=c["thr"], Xi0=c["Xi0"])
+    reg = cls(c["d"], c["order"], L_list=[c["L"]], threshold=c["thr"], constrain_constant=c["constrain_constant"],
+              beta0=c["beta0"], const0=c["const0"])
+    if own_Q:
+        with torch.no_grad():
+            reg.beta.copy_(reg.Q.T @ (c["Q"] @ c["beta0"]))          # orthonormal bases of the same subspace
+    else:
+        reg.Q = c["Q"]
+    return reg
