@@ -237,6 +237,88 @@ int symode_lbfgs_accept(const float* new_loss, const float* new_g, float* loss, 
                         const float* t, const float* prev_loss, long n_problems, int n, float tol_grad, float tol_change,
                         const float* params, float w_x, float w_reg, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Device-resident L-BFGS trainer: train_SIGED_lbfgs (non-latent branch) for n_problems independent problems with NOTHING
+ * on the host between two epochs.  An epoch is
+ *     closure, BEGIN-update, (closure, ACCEPT-update) x (max_iter - 1), epoch-end
+ * -- 2 max_iter + 1 launches: the closure is symode_loss_grad (or symode_loss_grad_reversed when gx / jgx are given), the
+ * update launches are the kernel of symode_lbfgs_accept_update extended by the coefficient map of the equivariance
+ * constraint (Xi = reshape(Q beta) + const and its chain rule, sindy.py:169-176, formed inside the launch), and the
+ * epoch-end launch is the per-epoch logic of train.py:697-725: NaN guard, the two update norms, convergence- / period-
+ * triggered thresholding (strict >, monotone, sindy.py:192-195) with optimiser reset, twice-converged stop.  Every epoch
+ * leaves one record per problem in `log` (and, with log_detail, the coefficients and mask after the epoch's events), which
+ * may be pinned host memory: the host reads it after synchronising on the epoch and produces the reference's prints,
+ * wandb record and checkpoints from it.
+ * replaces: train.py:630-725 (torch.optim.LBFGS.step + the epoch logic), per seed. */
+typedef struct symode_trainer {
+    /* closure data, read only: S = n_problems problems back to back */
+    const float* x;            /* (S, n_points, d) */
+    const float* dx;           /* (S, n_points, d) */
+    const float* gx;           /* (S, n_g, n_points, d) reversed-regulariser operands, or NULL (plain MSE closure) */
+    const float* jgx;          /* (S, n_g, n_points, d, d) */
+    int n_g;
+    float w_sym;               /* regulariser weight relative to the MSE: data term = mse + w_sym * regulariser */
+    long n_problems, n_points;
+    int d, order, flags;
+    float inv_count;           /* 1 / (points over all ranks * d) */
+    void* workspace;           /* reduction scratch of the closure kernel (symode_workspace_bytes / _init) */
+    size_t workspace_bytes;
+    /* parametrisation */
+    const float* q_eff;        /* (d p, r) row-major: Q with rows in Xi's (d, p) order; NULL = unconstrained (params are Xi) */
+    int r;                     /* columns of Q */
+    int allow_constant;        /* const is added to column 0 of Xi (sindy.py:173-175) */
+    int n_params;              /* d p, or r + d under the constraint */
+    /* objective  w_x * data + w_reg * |params|_1  (l1 != 0) and torch.optim.LBFGS's settings */
+    float w_x, w_reg;
+    int l1;
+    float lr, tol_grad, tol_change;
+    int max_iter, history;
+    /* epoch logic (train.py:697-725) */
+    float threshold, tol_update, near_band;
+    int st_freq;
+    /* state: ONE device allocation of symode_trainer_layout(...) bytes, prepared by symode_trainer_init */
+    void* state;
+    size_t state_bytes;
+    /* per-epoch records, ring of log_epochs epochs (device-visible memory; pinned host memory allowed):
+     *   log        (log_epochs, S, 8): [event code, mse, regulariser, |params|_1 of the last closure, update norm,
+     *              update norm vs the last convergence, near-threshold coefficients at this event, epoch]
+     *              event code: 0 none, 1 threshold on convergence, 2 threshold on st_freq, 3 final convergence, 4 NaN,
+     *              -1 problem already finished
+     *   log_test   (log_epochs, S, 2): closure value at the epoch's final coefficients and mask (train.py:739-751), written
+     *              by symode_trainer_run(..., test_eval != 0)
+     *   log_xi, log_mask (log_epochs, S, d p) and log_params (log_epochs, S, n_params), or all NULL: coefficients, mask and
+     *              parameters after the epoch's events */
+    float* log;
+    float* log_test;
+    float* log_xi;
+    float* log_mask;
+    float* log_params;
+    int log_epochs;
+} symode_trainer;
+
+#define SYMODE_TRAINER_FIELDS 29
+/* Byte offsets of the state block's arrays (offsets_out[SYMODE_TRAINER_FIELDS], may be NULL) and its total size.  Order:
+ * params, xi, mask, cl_loss (S, 2), cl_grad (S, d p), g, loss, act (u8), n_iter (i64), d, t, old_dirs, old_stps, ro, head
+ * (i64), count (i64), h_diag, prev_g, prev_loss, prev, pprev, n_iters (i32), done (u8), nan (u8), finished (u8), epochs
+ * (i32), near (i32), l1_last, test_grad (S, d p); fp32 unless stated.  Unconstrained problems keep ONE array for params and xi.  cl_loss and
+ * cl_grad are adjacent: a sharded run sums [cl_loss | cl_grad] over the ranks between closure and update. */
+size_t symode_trainer_layout(long n_problems, int n_params, int dp, int history, int constrained, size_t* offsets_out);
+
+/* Prepare the state block: zero it, h_diag = 1, params = prev = pprev = params0 (S, n_params), mask = mask0 (S, d p; NULL =
+ * ones), xi from params.  params0 / mask0 may be host or device pointers (copied with hipMemcpyAsync). */
+int symode_trainer_init(const symode_trainer* T, const float* params0, const float* mask0, void* stream);
+
+/* The three launches of an epoch on their own (a sharded run all-reduces [cl_loss | cl_grad] between closure and update).
+ * symode_trainer_closure: loss_out / grad_out NULL = the state's cl_loss / cl_grad.  symode_trainer_update: mode 2 = BEGIN
+ * (first iteration of an optimiser step), 1 = ACCEPT (all later ones). */
+int symode_trainer_closure(const symode_trainer* T, float* loss_out, float* grad_out, void* stream);
+int symode_trainer_update(const symode_trainer* T, int mode, void* stream);
+int symode_trainer_epoch_end(const symode_trainer* T, int epoch, void* stream);
+
+/* n_epochs whole epochs starting at epoch0, enqueued back to back; test_eval != 0 adds one closure launch per epoch into
+ * log_test.  Problems that finished earlier cost empty launches only. */
+int symode_trainer_run(const symode_trainer* T, int epoch0, int n_epochs, int test_eval, void* stream);
+
 /* HOST function (no GPU work): least squares on the normal equations G = A^T A (n, n), C = A^T b (n, k), fp64
  * row-major host arrays; A had m_rows rows.  driver 0 = LAPACK gelsy semantics (pivoted QR rank rule with
  * rcond < 0 -> torch's default eps_fp32 * max(m_rows, n), minimum-norm solution), driver 1 = gels (full rank).

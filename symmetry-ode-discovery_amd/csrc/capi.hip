@@ -17,7 +17,9 @@ const LibOps* find_ops(int d, int order, int flags) {
         SYMODE_CASE(1, 1) SYMODE_CASE(1, 2) SYMODE_CASE(1, 3) SYMODE_CASE(1, 4) SYMODE_CASE(1, 5)
         SYMODE_CASE(2, 1) SYMODE_CASE(2, 2) SYMODE_CASE(2, 3) SYMODE_CASE(2, 4) SYMODE_CASE(2, 5)
         SYMODE_CASE(3, 1) SYMODE_CASE(3, 2) SYMODE_CASE(3, 3) SYMODE_CASE(3, 4)
+#ifdef SYMODE_WITH_D4                                 // `make ALL=1`: no task of the reference has four state variables
         SYMODE_CASE(4, 1) SYMODE_CASE(4, 2) SYMODE_CASE(4, 3)
+#endif
         default: return nullptr;                      // (d, order) outside the compiled set
     }
 #undef SYMODE_CASE
@@ -110,7 +112,7 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
 
 extern "C" {
 
-int symode_abi_version(void) { return 2; }
+int symode_abi_version(void) { return 3; }
 
 const char* symode_error_string(int code) {
     switch (code) {

@@ -110,14 +110,38 @@ __device__ __forceinline__ float wave_amax(float v) {
 // gradient, stopping tests) and carries on into this one if the problem is still active -- between two closure
 // evaluations the optimiser is then ONE launch, and the accepted gradient never leaves the registers.
 struct AcceptArgs {
-    const float* new_loss;   // (S)     closure value at the moved parameters
-    const float* new_g;      // (S, n)  its gradient
+    const float* new_loss;   // (S)     closure value at the moved parameters [(S, 2) = (mse, regulariser) with w_pair != 0]
+    const float* new_g;      // (S, n)  its gradient [(S, d p) = d/dXi under a coefficient map, see XiMap]
     float tol_grad;
     int l1;                  // != 0: new_loss / new_g are the bare data term, objective = w_x * data + w_reg * |params|_1
     float w_x, w_reg;
+    int pair;                // != 0: new_loss holds (mse, regulariser) per problem, data term = mse + w_pair * regulariser
+    float w_pair;
 };
 
-template <int NC, bool ACCEPT>
+// The trainer's parametrisation of the coefficients (sindy.py:169-176): under the equivariance constraint the
+// optimisation variables are [beta (r) | const (d)] and Xi (d, p) = reshape(Q beta) (+ const in column 0); q holds Q with
+// its rows permuted into Xi's (d, p) row-major order (the host does the view / transpose of sindy.py:171-173 once).  The
+// closure kernel reads Xi and returns d/dXi, so the optimiser launch converts on both sides: gradient in (Q^T g_xi, and
+// g_xi[:, 0] for const), coefficients out after every move.  q == nullptr: Xi IS the parameter vector.
+struct XiMap {
+    const float* q;          // (d p, r) row-major, or nullptr
+    float* xi;               // (S, d p): Xi at the current parameters, rewritten after every move
+    int r, dp, p, allow_const;
+};
+
+// Trainer-only extras (nullptr in the sweep's tensor-op callers): problems the epoch logic has finished are skipped by
+// the BEGIN launch; the L1 norm of the parameters the last closure was evaluated at is kept for the epoch's log record.
+struct TrainerHook {
+    const unsigned char* done;
+    float* l1_last;
+};
+
+constexpr int LB_PLAIN = 0;    // update only: g / loss already hold this iteration's values
+constexpr int LB_ACCEPT = 1;   // finish the previous iteration (take the re-evaluated loss / gradient, stopping tests), then update
+constexpr int LB_BEGIN = 2;    // first iteration of an optimiser step: take the closure's loss / gradient, optimality test, then update
+
+template <int NC, int MODE>
 __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ params, float* __restrict__ g,
                                                             float* __restrict__ loss, unsigned char* __restrict__ act,
                                                             long* __restrict__ n_iter, float* __restrict__ d,
@@ -126,28 +150,53 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
                                                             long* __restrict__ head, long* __restrict__ count,
                                                             float* __restrict__ h_diag, float* __restrict__ prev_g,
                                                             float* __restrict__ prev_loss, int n, int H, float lr,
-                                                            float tol_change, AcceptArgs acc) {
+                                                            float tol_change, AcceptArgs acc, XiMap map, TrainerHook hook) {
     constexpr bool STAGED = NC > 0;
+    constexpr bool ACCEPT = MODE == LB_ACCEPT, BEGIN = MODE == LB_BEGIN;
     __shared__ float al[LB_MAXH];
+    __shared__ float cvt[WAVE * LB_MAXC];                    // coefficient map: d/dXi on the way in, parameters on the way out
     extern __shared__ float staged[];                        // STAGED: pad [n] | Y [H][n] | S [H][n] | ro [H] | 256 floats of padding
     const long s = blockIdx.x;
     const int lane = threadIdx.x;
-    if (!__builtin_amdgcn_readfirstlane((int)act[s])) return;   // wave-uniform: this problem stopped earlier
+    if constexpr (BEGIN) {
+        if (hook.done != nullptr && __builtin_amdgcn_readfirstlane((int)hook.done[s])) {   // finished by the epoch logic
+            if (lane == 0) act[s] = 0;
+            return;
+        }
+    } else {
+        if (!__builtin_amdgcn_readfirstlane((int)act[s])) return;   // wave-uniform: this problem stopped earlier
+    }
     float* const ldsY = staged + n;                          // (a row of padding in front: the loops prefetch row -1)
     float* const ldsS = ldsY + H * n;
     float* const ldsR = ldsS + H * n;
     float gv[LB_MAXC], q[LB_MAXC];
     float loss_s;
-    if constexpr (ACCEPT) {
-        const float tt = t[s];
-        float nl = acc.new_loss[s];
+    if constexpr (ACCEPT || BEGIN) {
+        const float tt = BEGIN ? 0.0f : t[s];
+        float nl = acc.pair ? fmaf(acc.w_pair, acc.new_loss[2 * s + 1], acc.new_loss[2 * s]) : acc.new_loss[s];
         float gmax = 0.0f, dmax = 0.0f, p_l1 = 0.0f;
+        if (map.q != nullptr) {                              // d/dXi (d p) -> LDS; each lane then forms its parameter's gradient
+#pragma unroll
+            for (int c = 0; c < LB_MAXC; ++c) {
+                const int j = lane + WAVE * c;
+                if (j < map.dp) cvt[j] = acc.new_g[s * map.dp + j];
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int c = 0; c < LB_MAXC; ++c) {
             const int i = lane + WAVE * c;
             gv[c] = 0.0f;
             if (i < n) {
-                float v = acc.new_g[s * n + i];
+                float v;
+                if (map.q == nullptr) {
+                    v = acc.new_g[s * n + i];
+                } else if (i < map.r) {                      // (Q^T g_xi)_i, summed in row order
+                    v = 0.0f;
+                    for (int j = 0; j < map.dp; ++j) v = fmaf(map.q[j * map.r + i], cvt[j], v);
+                } else {                                     // const_i: column 0 of equation i (zero when the model does not read it)
+                    v = map.allow_const ? cvt[(i - map.r) * map.p] : 0.0f;
+                }
                 if (acc.l1) {
                     const float pv = params[s * n + i];
                     const float sg = (float)(pv > 0.0f) - (float)(pv < 0.0f);
@@ -156,15 +205,23 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
                 }
                 g[s * n + i] = v;
                 gv[c] = v;
-                const float av = fabsf(v), ad = fabsf(d[s * n + i] * tt);
+                const float av = fabsf(v), ad = BEGIN ? 1.0f : fabsf(d[s * n + i] * tt);
                 gmax = (av != av || gmax != gmax) ? __builtin_nanf("") : fmaxf(gmax, av);
                 dmax = (ad != ad || dmax != dmax) ? __builtin_nanf("") : fmaxf(dmax, ad);
             }
         }
         gmax = wave_amax(gmax);
         dmax = wave_amax(dmax);
-        if (acc.l1) nl = __fadd_rn(__fmul_rn(acc.w_x, nl), __fmul_rn(acc.w_reg, wave_sum(p_l1)));
-        const bool stop = (gmax <= acc.tol_grad) || (dmax <= tol_change) || (fabsf(nl - prev_loss[s]) < tol_change);
+        if (acc.l1) {
+            const float l1 = wave_sum(p_l1);
+            nl = __fadd_rn(__fmul_rn(acc.w_x, nl), __fmul_rn(acc.w_reg, l1));
+            if (hook.l1_last != nullptr && lane == 0) hook.l1_last[s] = l1;
+        }
+        // BEGIN: torch's "optimal condition" at the top of step() -- `if flat_grad.abs().max() <= tolerance_grad: return`,
+        // i.e. a NaN gradient does NOT stop the step (the parameters go to NaN and the epoch logic's NaN guard ends the
+        // run, train.py:697); ACCEPT: its three tests after the re-evaluation.
+        const bool stop = BEGIN ? (gmax <= acc.tol_grad)
+                                : ((gmax <= acc.tol_grad) || (dmax <= tol_change) || (fabsf(nl - prev_loss[s]) < tol_change));
         if (lane == 0) loss[s] = nl;
         if (__builtin_amdgcn_readfirstlane((int)stop)) {
             if (lane == 0) act[s] = 0;
@@ -363,13 +420,31 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
     const float tn = first ? fminf(1.0f, 1.0f / wave_sum_dpp_uniform(p_abs)) * lr : lr;
     const float gtd = wave_sum_dpp_uniform(p_gtd);
     const bool live = !(gtd > -tol_change);
+    if (map.q != nullptr && live) __syncthreads();           // (cvt still holds d/dXi of this launch's first half)
 #pragma unroll
     for (int c = 0; c < LB_MAXC; ++c) {
         const int i = lane + WAVE * c;
         if (i < n) {
             d[s * n + i] = q[c];
             prev_g[s * n + i] = gv[c];
-            if (live) params[s * n + i] = __fadd_rn(params[s * n + i], __fmul_rn(tn, q[c]));
+            if (live) {
+                const float moved = __fadd_rn(params[s * n + i], __fmul_rn(tn, q[c]));
+                params[s * n + i] = moved;
+                if (map.q != nullptr) cvt[i] = moved;
+            }
+        }
+    }
+    if (map.q != nullptr && live) {                          // Xi at the moved parameters for the next closure launch
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int j = lane + WAVE * c;
+            if (j < map.dp) {
+                float v = 0.0f;
+                for (int k = 0; k < map.r; ++k) v = fmaf(map.q[j * map.r + k], cvt[k], v);
+                if (map.allow_const && j % map.p == 0) v += cvt[map.r + j / map.p];
+                map.xi[s * map.dp + j] = v;
+            }
         }
     }
     if (lane == 0) {
@@ -462,26 +537,26 @@ extern "C" int symode_selftest_wave_sum(const float* in, float* butterfly_out, f
 }
 
 namespace symode {
-inline int launch_lbfgs_update(bool accept, float* params, float* g, float* loss, unsigned char* act, long* n_iter, float* d, float* t,
+inline int launch_lbfgs_update(int mode, float* params, float* g, float* loss, unsigned char* act, long* n_iter, float* d, float* t,
                                float* old_dirs, float* old_stps, float* ro, long* head, long* count, float* h_diag, float* prev_g,
                                float* prev_loss, long n_problems, int n, int history, float lr, float tol_change, AcceptArgs acc,
-                               void* stream) {
+                               XiMap map, TrainerHook hook, void* stream) {
     if (n_problems < 1 || n < 1 || n > WAVE * LB_MAXC || history < 1 || history > LB_MAXH) return SYMODE_E_BADSIZE;
     if (!params || !g || !loss || !act || !n_iter || !d || !t || !old_dirs || !old_stps || !ro || !head || !count || !h_diag ||
-        !prev_g || !prev_loss || (accept && (!acc.new_loss || !acc.new_g)))
+        !prev_g || !prev_loss || (mode != LB_PLAIN && (!acc.new_loss || !acc.new_g)))
         return SYMODE_E_NULLPTR;
+    if (map.q != nullptr && (!map.xi || map.dp < 1 || map.dp > WAVE * LB_MAXC || map.r < 0 || map.r > n || map.p < 1)) return SYMODE_E_BADSIZE;
     const size_t stage_bytes = (((size_t)2 * n + 1) * history + n + 256) * sizeof(float);
     const int nc = stage_bytes <= 60 * 1024 ? (n + WAVE - 1) / WAVE : 0;
+#define SYMODE_LBFGS_LAUNCH(NC_, MODE_, BYTES_)                                                                                   \
+    lbfgs_update_kernel<NC_, MODE_><<<dim3((unsigned)n_problems), dim3(WAVE), BYTES_, (hipStream_t)stream>>>(                     \
+        params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history, lr,       \
+        tol_change, acc, map, hook)
 #define SYMODE_LBFGS_UPDATE(NC_, BYTES_)                                                                                          \
     do {                                                                                                                          \
-        if (accept)                                                                                                               \
-            lbfgs_update_kernel<NC_, true><<<dim3((unsigned)n_problems), dim3(WAVE), BYTES_, (hipStream_t)stream>>>(              \
-                params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history,   \
-                lr, tol_change, acc);                                                                                             \
-        else                                                                                                                      \
-            lbfgs_update_kernel<NC_, false><<<dim3((unsigned)n_problems), dim3(WAVE), BYTES_, (hipStream_t)stream>>>(             \
-                params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g, prev_loss, n, history,   \
-                lr, tol_change, acc);                                                                                             \
+        if (mode == LB_ACCEPT) SYMODE_LBFGS_LAUNCH(NC_, LB_ACCEPT, BYTES_);                                                       \
+        else if (mode == LB_BEGIN) SYMODE_LBFGS_LAUNCH(NC_, LB_BEGIN, BYTES_);                                                    \
+        else SYMODE_LBFGS_LAUNCH(NC_, LB_PLAIN, BYTES_);                                                                          \
     } while (0)
     switch (nc) {
         case 1: SYMODE_LBFGS_UPDATE(1, stage_bytes); break;
@@ -491,6 +566,7 @@ inline int launch_lbfgs_update(bool accept, float* params, float* g, float* loss
         default: SYMODE_LBFGS_UPDATE(0, 0); break;
     }
 #undef SYMODE_LBFGS_UPDATE
+#undef SYMODE_LBFGS_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SYMODE_OK : (int)e;
 }
@@ -500,9 +576,11 @@ extern "C" int symode_lbfgs_update(float* params, const float* g, const float* l
                                    float* t, float* old_dirs, float* old_stps, float* ro, long* head, long* count,
                                    float* h_diag, float* prev_g, float* prev_loss, long n_problems, int n, int history,
                                    float lr, float tol_change, void* stream) {
-    return symode::launch_lbfgs_update(false, params, const_cast<float*>(g), const_cast<float*>(loss), act, n_iter, d, t, old_dirs,
-                                       old_stps, ro, head, count, h_diag, prev_g, prev_loss, n_problems, n, history, lr, tol_change,
-                                       symode::AcceptArgs{nullptr, nullptr, 0.0f, 0, 1.0f, 0.0f}, stream);
+    using namespace symode;
+    return launch_lbfgs_update(LB_PLAIN, params, const_cast<float*>(g), const_cast<float*>(loss), act, n_iter, d, t, old_dirs,
+                               old_stps, ro, head, count, h_diag, prev_g, prev_loss, n_problems, n, history, lr, tol_change,
+                               AcceptArgs{nullptr, nullptr, 0.0f, 0, 1.0f, 0.0f, 0, 0.0f}, XiMap{nullptr, nullptr, 0, 0, 1, 0},
+                               TrainerHook{nullptr, nullptr}, stream);
 }
 
 extern "C" int symode_lbfgs_accept_update(const float* new_loss, const float* new_g, float tol_grad, int l1, float w_x, float w_reg,
@@ -510,9 +588,11 @@ extern "C" int symode_lbfgs_accept_update(const float* new_loss, const float* ne
                                           float* t, float* old_dirs, float* old_stps, float* ro, long* head, long* count,
                                           float* h_diag, float* prev_g, float* prev_loss, long n_problems, int n, int history,
                                           float lr, float tol_change, void* stream) {
-    return symode::launch_lbfgs_update(true, params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g,
-                                       prev_loss, n_problems, n, history, lr, tol_change,
-                                       symode::AcceptArgs{new_loss, new_g, tol_grad, l1, w_x, w_reg}, stream);
+    using namespace symode;
+    return launch_lbfgs_update(LB_ACCEPT, params, g, loss, act, n_iter, d, t, old_dirs, old_stps, ro, head, count, h_diag, prev_g,
+                               prev_loss, n_problems, n, history, lr, tol_change,
+                               AcceptArgs{new_loss, new_g, tol_grad, l1, w_x, w_reg, 0, 0.0f}, XiMap{nullptr, nullptr, 0, 0, 1, 0},
+                               TrainerHook{nullptr, nullptr}, stream);
 }
 
 extern "C" int symode_lbfgs_accept(const float* new_loss, const float* new_g, float* loss, float* g, unsigned char* act,
@@ -526,4 +606,317 @@ extern "C" int symode_lbfgs_accept(const float* new_loss, const float* new_g, fl
         new_loss, new_g, loss, g, act, d, t, prev_loss, n, tol_grad, tol_change, params, w_x, w_reg);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SYMODE_OK : (int)e;
+}
+
+// =====================================================================================================================
+// Device-resident trainer (include/symode.h, "Device-resident L-BFGS trainer")
+// =====================================================================================================================
+namespace symode {
+
+enum TrainerField {
+    TF_PARAMS, TF_XI, TF_MASK, TF_CL_LOSS, TF_CL_GRAD, TF_G, TF_LOSS, TF_ACT, TF_N_ITER, TF_D, TF_T, TF_OLD_DIRS, TF_OLD_STPS,
+    TF_RO, TF_HEAD, TF_COUNT, TF_H_DIAG, TF_PREV_G, TF_PREV_LOSS, TF_PREV, TF_PPREV, TF_N_ITERS, TF_DONE, TF_NAN, TF_FINISHED,
+    TF_EPOCHS, TF_NEAR, TF_L1_LAST, TF_TEST_GRAD, TF_COUNT_FIELDS
+};
+static_assert(TF_COUNT_FIELDS == SYMODE_TRAINER_FIELDS, "symode.h and the trainer disagree on the state layout");
+
+inline size_t trainer_layout(long S, int n, int dp, int H, bool constrained, size_t* off) {
+    const size_t f = sizeof(float);
+    const size_t bytes[TF_COUNT_FIELDS] = {
+        (size_t)S * n * f,              // params
+        constrained ? (size_t)S * dp * f : 0,   // xi (unconstrained: the params array)
+        (size_t)S * dp * f,             // mask
+        (size_t)S * 2 * f,              // cl_loss
+        (size_t)S * dp * f,             // cl_grad
+        (size_t)S * n * f,              // g
+        (size_t)S * f,                  // loss
+        (size_t)S,                      // act
+        (size_t)S * 8,                  // n_iter
+        (size_t)S * n * f,              // d
+        (size_t)S * f,                  // t
+        (size_t)S * H * n * f,          // old_dirs
+        (size_t)S * H * n * f,          // old_stps
+        (size_t)S * H * f,              // ro
+        (size_t)S * 8,                  // head
+        (size_t)S * 8,                  // count
+        (size_t)S * f,                  // h_diag
+        (size_t)S * n * f,              // prev_g
+        (size_t)S * f,                  // prev_loss
+        (size_t)S * n * f,              // prev
+        (size_t)S * n * f,              // pprev
+        (size_t)S * 4,                  // n_iters
+        (size_t)S, (size_t)S, (size_t)S,   // done, nan, finished
+        (size_t)S * 4,                  // epochs
+        (size_t)S * 4,                  // near
+        (size_t)S * f,                  // l1_last
+        (size_t)S * dp * f,             // test_grad
+    };
+    size_t at = 0;
+    for (int k = 0; k < TF_COUNT_FIELDS; ++k) {
+        size_t here = at;
+        if (k == TF_XI && !constrained) here = 0;            // alias of params
+        if (k == TF_CL_GRAD) here = at;                      // (cl_loss is S * 8 bytes: cl_grad follows it without a gap)
+        if (off) off[k] = here;
+        at += bytes[k];
+        if (k != TF_CL_LOSS) at = (at + 255) & ~(size_t)255;
+    }
+    return at;
+}
+
+struct TrainerState {
+    float *params, *xi, *mask, *cl_loss, *cl_grad, *g, *loss;
+    unsigned char* act;
+    long* n_iter;
+    float *d, *t, *old_dirs, *old_stps, *ro;
+    long *head, *count;
+    float *h_diag, *prev_g, *prev_loss, *prev, *pprev;
+    int* n_iters;
+    unsigned char *done, *nan, *finished;
+    int *epochs, *near;
+    float *l1_last, *test_grad;
+};
+
+inline int trainer_state(const symode_trainer* T, TrainerState& st, int& dp) {
+    if (!T) return SYMODE_E_NULLPTR;
+    const int p = symode_lib_size(T->d, T->order, T->flags);
+    if (p < 0) return SYMODE_E_UNSUPPORTED;
+    dp = T->d * p;
+    const bool con = T->q_eff != nullptr;
+    if (T->n_problems < 1 || T->n_problems > 65535 || T->n_points < 1 || T->n_params != (con ? T->r + T->d : dp) || T->n_params > WAVE * LB_MAXC ||
+        dp > WAVE * LB_MAXC || T->history < 1 || T->history > LB_MAXH || T->max_iter < 1 || T->log_epochs < 1 || (con && T->r < 1))
+        return SYMODE_E_BADSIZE;
+    if (!T->x || !T->dx || !T->state || !T->log || !T->log_test || !T->workspace || (T->gx && !T->jgx)) return SYMODE_E_NULLPTR;
+    size_t off[TF_COUNT_FIELDS];
+    if (T->state_bytes < trainer_layout(T->n_problems, T->n_params, dp, T->history, con, off)) return SYMODE_E_WORKSPACE;
+    if (((uintptr_t)T->state % 256) != 0) return SYMODE_E_ALIGN;
+    char* b = (char*)T->state;
+    st.params = (float*)(b + off[TF_PARAMS]);       st.xi = (float*)(b + off[TF_XI]);           st.mask = (float*)(b + off[TF_MASK]);
+    st.cl_loss = (float*)(b + off[TF_CL_LOSS]);     st.cl_grad = (float*)(b + off[TF_CL_GRAD]); st.g = (float*)(b + off[TF_G]);
+    st.loss = (float*)(b + off[TF_LOSS]);           st.act = (unsigned char*)(b + off[TF_ACT]); st.n_iter = (long*)(b + off[TF_N_ITER]);
+    st.d = (float*)(b + off[TF_D]);                 st.t = (float*)(b + off[TF_T]);             st.old_dirs = (float*)(b + off[TF_OLD_DIRS]);
+    st.old_stps = (float*)(b + off[TF_OLD_STPS]);   st.ro = (float*)(b + off[TF_RO]);           st.head = (long*)(b + off[TF_HEAD]);
+    st.count = (long*)(b + off[TF_COUNT]);          st.h_diag = (float*)(b + off[TF_H_DIAG]);   st.prev_g = (float*)(b + off[TF_PREV_G]);
+    st.prev_loss = (float*)(b + off[TF_PREV_LOSS]); st.prev = (float*)(b + off[TF_PREV]);       st.pprev = (float*)(b + off[TF_PPREV]);
+    st.n_iters = (int*)(b + off[TF_N_ITERS]);       st.done = (unsigned char*)(b + off[TF_DONE]); st.nan = (unsigned char*)(b + off[TF_NAN]);
+    st.finished = (unsigned char*)(b + off[TF_FINISHED]); st.epochs = (int*)(b + off[TF_EPOCHS]); st.near = (int*)(b + off[TF_NEAR]);
+    st.l1_last = (float*)(b + off[TF_L1_LAST]);     st.test_grad = (float*)(b + off[TF_TEST_GRAD]);
+    return SYMODE_OK;
+}
+
+// h_diag = 1, mask = 1 (when no mask was handed over), Xi from the start parameters
+__global__ __launch_bounds__(WAVE) void trainer_init_kernel(const float* __restrict__ params, float* __restrict__ h_diag,
+                                                            float* __restrict__ mask, int fill_mask, XiMap map, int n) {
+    __shared__ float cvt[WAVE * LB_MAXC];
+    const long s = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (lane == 0) h_diag[s] = 1.0f;
+    if (fill_mask)
+        for (int j = lane; j < map.dp; j += WAVE) mask[s * map.dp + j] = 1.0f;
+    if (map.q == nullptr) return;
+    for (int i = lane; i < n; i += WAVE) cvt[i] = params[s * n + i];
+    __syncthreads();
+    for (int j = lane; j < map.dp; j += WAVE) {
+        float v = 0.0f;
+        for (int k = 0; k < map.r; ++k) v = fmaf(map.q[j * map.r + k], cvt[k], v);
+        if (map.allow_const && j % map.p == 0) v += cvt[map.r + j / map.p];
+        map.xi[s * map.dp + j] = v;
+    }
+}
+
+struct EpochArgs {
+    float *params, *prev, *pprev, *xi, *mask;
+    long *n_iter, *head, *count;
+    float* h_diag;
+    int* n_iters;
+    unsigned char *done, *nan, *finished;
+    int *epochs, *near;
+    const float *cl_loss, *l1_last;
+    float *log, *log_xi, *log_mask, *log_params;
+    int n, r, dp, pair, st_freq, epoch, slot;
+    float threshold, tol_update, near_band;
+};
+
+// The per-epoch logic of train.py:697-725 for one problem per wavefront (statement numbers of the reference in comments).
+__global__ __launch_bounds__(WAVE) void trainer_epoch_kernel(EpochArgs a) {
+    const long s = blockIdx.x;
+    const long S = gridDim.x;
+    const int lane = threadIdx.x;
+    float* rec = a.log + ((long)a.slot * S + s) * 8;
+    if (__builtin_amdgcn_readfirstlane((int)a.done[s])) {
+        if (lane == 0) { rec[0] = -1.0f; rec[7] = (float)a.epoch; }
+        return;
+    }
+    const int n = a.n, r_split = a.r > 0 ? a.r : n;           // constrained: two parameter tensors, beta (r) and const (d)
+    float sq1a = 0.0f, sq1b = 0.0f, sq2a = 0.0f, sq2b = 0.0f;
+    float pv[LB_MAXC];
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) {
+        const int i = lane + WAVE * c;
+        pv[c] = 0.0f;
+        if (i < n) {
+            const float v = a.params[s * n + i];
+            pv[c] = v;
+            bad |= (v != v);
+            const float d1 = v - a.prev[s * n + i], d2 = v - a.pprev[s * n + i];
+            if (i < r_split) { sq1a = fmaf(d1, d1, sq1a); sq2a = fmaf(d2, d2, sq2a); }
+            else             { sq1b = fmaf(d1, d1, sq1b); sq2b = fmaf(d2, d2, sq2b); }
+        }
+    }
+    const int n_it = a.n_iters[s] + 1;                                                   // :694
+    const bool is_nan = __builtin_amdgcn_readfirstlane((int)(__ballot(bad) != 0ull));    // :697
+    const float upd = sqrtf(wave_sum(sq1a)) + sqrtf(wave_sum(sq1b));                     // :702-704 (sum of per-tensor norms)
+    const float upd2 = sqrtf(wave_sum(sq2a)) + sqrtf(wave_sum(sq2b));                    // :706-708
+    const bool conv = !is_nan && upd < a.tol_update;                                     // :705
+    const bool final = conv && upd2 < a.tol_update;                                      // :709
+    const bool thr_conv = conv && !final;
+    const bool thr_freq = !is_nan && !conv && a.st_freq > 0 && n_it % a.st_freq == 0;    // :720
+    const bool ev = thr_conv || thr_freq;
+    int near_here = 0;
+    if (ev) {                                                                            // :716 / :722  set_threshold (sindy.py:192-195)
+#pragma unroll
+        for (int c = 0; c < LB_MAXC; ++c) {
+            const int j = lane + WAVE * c;
+            if (j < a.dp) {
+                const float av = fabsf(a.xi[s * a.dp + j]), m = a.mask[s * a.dp + j];
+                near_here += (fabsf(av - a.threshold) < a.near_band) && (m > 0.0f);
+                a.mask[s * a.dp + j] = (av > a.threshold && m > 0.0f) ? 1.0f : 0.0f;     // strict >, monotone
+            }
+        }
+        near_here = (int)wave_sum((float)near_here);
+    }
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) {
+        const int i = lane + WAVE * c;
+        if (i < n) {
+            if (thr_conv) a.pprev[s * n + i] = pv[c];                                    // :718
+            if (!is_nan && !final) a.prev[s * n + i] = pv[c];                            // :725
+        }
+    }
+    if (a.log_xi != nullptr) {
+        float* lx = a.log_xi + ((long)a.slot * S + s) * a.dp;
+        float* lm = a.log_mask + ((long)a.slot * S + s) * a.dp;
+        for (int j = lane; j < a.dp; j += WAVE) {
+            lx[j] = a.xi[s * a.dp + j];
+            lm[j] = a.mask[s * a.dp + j];
+        }
+        float* lp = a.log_params + ((long)a.slot * S + s) * n;
+        for (int i = lane; i < n; i += WAVE) lp[i] = a.params[s * n + i];
+    }
+    if (lane == 0) {
+        a.epochs[s] = a.epoch + 1;
+        a.n_iters[s] = ev ? 0 : n_it;
+        if (ev) {                                                                        // :717 / :723  a fresh optimiser
+            a.n_iter[s] = 0;
+            a.head[s] = 0;
+            a.count[s] = 0;
+            a.h_diag[s] = 1.0f;
+            a.near[s] += near_here;
+        }
+        if (is_nan) { a.nan[s] = 1; a.done[s] = 1; }
+        if (final) { a.finished[s] = 1; a.done[s] = 1; }
+        rec[0] = is_nan ? 4.0f : final ? 3.0f : thr_conv ? 1.0f : thr_freq ? 2.0f : 0.0f;
+        rec[1] = a.pair ? a.cl_loss[2 * s] : a.cl_loss[s];
+        rec[2] = a.pair ? a.cl_loss[2 * s + 1] : 0.0f;
+        rec[3] = a.l1_last[s];
+        rec[4] = upd;
+        rec[5] = upd2;
+        rec[6] = (float)near_here;
+        rec[7] = (float)a.epoch;
+    }
+}
+
+inline XiMap trainer_map(const symode_trainer* T, const TrainerState& st, int dp) {
+    return XiMap{T->q_eff, st.xi, T->r, dp, dp / T->d, T->allow_constant};
+}
+
+}  // namespace symode
+
+extern "C" size_t symode_trainer_layout(long n_problems, int n_params, int dp, int history, int constrained, size_t* offsets_out) {
+    if (n_problems < 1 || n_params < 1 || dp < 1 || history < 1) return 0;
+    return symode::trainer_layout(n_problems, n_params, dp, history, constrained != 0, offsets_out);
+}
+
+extern "C" int symode_trainer_init(const symode_trainer* T, const float* params0, const float* mask0, void* stream) {
+    using namespace symode;
+    TrainerState st;
+    int dp;
+    if (int rc = trainer_state(T, st, dp)) return rc;
+    if (!params0) return SYMODE_E_NULLPTR;
+    hipStream_t hs = (hipStream_t)stream;
+    const long S = T->n_problems;
+    const size_t pb = (size_t)S * T->n_params * sizeof(float);
+    hipError_t e = hipMemsetAsync(T->state, 0, T->state_bytes, hs);
+    if (e == hipSuccess) e = hipMemcpyAsync(st.params, params0, pb, hipMemcpyDefault, hs);
+    if (e == hipSuccess) e = hipMemcpyAsync(st.prev, params0, pb, hipMemcpyDefault, hs);
+    if (e == hipSuccess) e = hipMemcpyAsync(st.pprev, params0, pb, hipMemcpyDefault, hs);
+    if (e == hipSuccess && mask0) e = hipMemcpyAsync(st.mask, mask0, (size_t)S * dp * sizeof(float), hipMemcpyDefault, hs);
+    if (e != hipSuccess) return (int)e;
+    trainer_init_kernel<<<dim3((unsigned)S), dim3(WAVE), 0, hs>>>(st.params, st.h_diag, st.mask, mask0 ? 0 : 1, trainer_map(T, st, dp),
+                                                                  T->n_params);
+    e = hipGetLastError();
+    return e == hipSuccess ? SYMODE_OK : (int)e;
+}
+
+extern "C" int symode_trainer_closure(const symode_trainer* T, float* loss_out, float* grad_out, void* stream) {
+    using namespace symode;
+    TrainerState st;
+    int dp;
+    if (int rc = trainer_state(T, st, dp)) return rc;
+    float* lo = loss_out ? loss_out : st.cl_loss;
+    float* go = grad_out ? grad_out : st.cl_grad;
+    if (T->gx != nullptr)
+        return symode_loss_grad_reversed(T->x, T->dx, T->gx, T->jgx, T->n_g, T->n_problems, T->n_points, T->d, T->order, T->flags,
+                                         st.xi, st.mask, T->inv_count, T->w_sym, lo, go, T->workspace, T->workspace_bytes, stream);
+    return symode_loss_grad(T->x, T->dx, T->n_problems, T->n_points, T->d, T->order, T->flags, st.xi, st.mask, T->inv_count, lo, go,
+                            T->workspace, T->workspace_bytes, stream);
+}
+
+extern "C" int symode_trainer_update(const symode_trainer* T, int mode, void* stream) {
+    using namespace symode;
+    TrainerState st;
+    int dp;
+    if (int rc = trainer_state(T, st, dp)) return rc;
+    if (mode != LB_ACCEPT && mode != LB_BEGIN) return SYMODE_E_BADSIZE;
+    const int pair = T->gx != nullptr;
+    return launch_lbfgs_update(mode, st.params, st.g, st.loss, st.act, st.n_iter, st.d, st.t, st.old_dirs, st.old_stps, st.ro, st.head,
+                               st.count, st.h_diag, st.prev_g, st.prev_loss, T->n_problems, T->n_params, T->history, T->lr, T->tol_change,
+                               AcceptArgs{st.cl_loss, st.cl_grad, T->tol_grad, 1, T->w_x, T->l1 ? T->w_reg : 0.0f, pair, T->w_sym},
+                               trainer_map(T, st, dp), TrainerHook{st.done, st.l1_last}, stream);
+}
+
+extern "C" int symode_trainer_epoch_end(const symode_trainer* T, int epoch, void* stream) {
+    using namespace symode;
+    TrainerState st;
+    int dp;
+    if (int rc = trainer_state(T, st, dp)) return rc;
+    if (epoch < 0) return SYMODE_E_BADSIZE;
+    if ((T->log_xi == nullptr) != (T->log_mask == nullptr) || (T->log_xi == nullptr) != (T->log_params == nullptr)) return SYMODE_E_NULLPTR;
+    EpochArgs a{st.params, st.prev, st.pprev, st.xi, st.mask, st.n_iter, st.head, st.count, st.h_diag, st.n_iters, st.done, st.nan,
+                st.finished, st.epochs, st.near, st.cl_loss, st.l1_last, T->log, T->log_xi, T->log_mask, T->log_params, T->n_params,
+                T->q_eff ? T->r : 0, dp, T->gx != nullptr, T->st_freq, epoch, epoch % T->log_epochs, T->threshold, T->tol_update,
+                T->near_band};
+    trainer_epoch_kernel<<<dim3((unsigned)T->n_problems), dim3(WAVE), 0, (hipStream_t)stream>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SYMODE_OK : (int)e;
+}
+
+extern "C" int symode_trainer_run(const symode_trainer* T, int epoch0, int n_epochs, int test_eval, void* stream) {
+    using namespace symode;
+    TrainerState st;
+    int dp;
+    if (int rc = trainer_state(T, st, dp)) return rc;
+    if (epoch0 < 0 || n_epochs < 0) return SYMODE_E_BADSIZE;
+    for (int e = epoch0; e < epoch0 + n_epochs; ++e) {
+        for (int it = 0; it < T->max_iter; ++it) {           // torch.optim.LBFGS.step: max_iter moves, max_iter evaluations
+            if (int rc = symode_trainer_closure(T, nullptr, nullptr, stream)) return rc;
+            if (int rc = symode_trainer_update(T, it == 0 ? LB_BEGIN : LB_ACCEPT, stream)) return rc;
+        }
+        if (int rc = symode_trainer_epoch_end(T, e, stream)) return rc;
+        if (test_eval) {
+            const long slot = e % T->log_epochs;
+            if (int rc = symode_trainer_closure(T, T->log_test + slot * T->n_problems * 2, st.test_grad, stream)) return rc;
+        }
+    }
+    return SYMODE_OK;
 }

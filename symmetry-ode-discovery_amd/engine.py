@@ -67,12 +67,36 @@ _SIGNATURES = {
     "symode_lbfgs_accept_update": (c_int, [c_void_p, c_void_p, c_float, c_int, c_float, c_float] + [c_void_p] * 15
                                    + [c_long, c_int, c_int, c_float, c_float, c_void_p]),
     "symode_lbfgs_accept": (c_int, [c_void_p] * 8 + [c_long, c_int, c_float, c_float, c_void_p, c_float, c_float, c_void_p]),
+    "symode_trainer_layout": (c_size_t, [c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    "symode_trainer_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "symode_trainer_closure": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "symode_trainer_update": (c_int, [c_void_p, c_int, c_void_p]),
+    "symode_trainer_epoch_end": (c_int, [c_void_p, c_int, c_void_p]),
+    "symode_trainer_run": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "symode_host_stlsq_sweep": (c_int, [c_void_p, c_int, c_int, c_int, c_long, ctypes.c_double, ctypes.c_double, c_int, c_int,
                                         ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+
+
+class TrainerDesc(ctypes.Structure):
+    """``symode_trainer`` of include/symode.h, field for field."""
+    _fields_ = [("x", c_void_p), ("dx", c_void_p), ("gx", c_void_p), ("jgx", c_void_p), ("n_g", c_int), ("w_sym", c_float),
+                ("n_problems", c_long), ("n_points", c_long), ("d", c_int), ("order", c_int), ("flags", c_int),
+                ("inv_count", c_float), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+                ("q_eff", c_void_p), ("r", c_int), ("allow_constant", c_int), ("n_params", c_int),
+                ("w_x", c_float), ("w_reg", c_float), ("l1", c_int), ("lr", c_float), ("tol_grad", c_float), ("tol_change", c_float),
+                ("max_iter", c_int), ("history", c_int),
+                ("threshold", c_float), ("tol_update", c_float), ("near_band", c_float), ("st_freq", c_int),
+                ("state", c_void_p), ("state_bytes", c_size_t),
+                ("log", c_void_p), ("log_test", c_void_p), ("log_xi", c_void_p), ("log_mask", c_void_p), ("log_params", c_void_p), ("log_epochs", c_int)]
+
+
+TRAINER_FIELDS = ("params", "xi", "mask", "cl_loss", "cl_grad", "g", "loss", "act", "n_iter", "d", "t", "old_dirs", "old_stps", "ro",
+                  "head", "count", "h_diag", "prev_g", "prev_loss", "prev", "pprev", "n_iters", "done", "nan", "finished", "epochs",
+                  "near", "l1_last", "test_grad")
 
 
 class SymodeError(RuntimeError):

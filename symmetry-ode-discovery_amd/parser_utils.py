@@ -46,7 +46,10 @@ _MAIN_ARGS = [
     ("sindy_optimizer", _S, "adam"), ("lbfgs_subsample", _F, 1.0),
     # least-squares driver of the STLSQ solves (new flag): gels = torch.linalg.lstsq on a GPU (default here),
     # gelsy = its rank-truncating CPU default
-    ("lstsq_driver", _S, None), ("device_lbfgs", _FLAG, None),
+    ("lstsq_driver", _S, None),
+    # L-BFGS fits run optimiser + epoch logic on the device by default; --torch_lbfgs selects torch.optim.LBFGS's own
+    # sequence of tensor operations on host-resident variables instead (--device_lbfgs: accepted, the default now)
+    ("device_lbfgs", _FLAG, None), ("torch_lbfgs", _FLAG, None),
     # PySR (accepted for config compatibility; that path is out of scope)
     ("pysr_subsample", _F, 1.0), ("pysr_bs", _I, 1000), ("pysr_symmreg", _FLAG, None),
     # run settings

@@ -32,6 +32,11 @@ from .lstsq import lstsq_normal
 # a coefficient that lands within this band of the threshold could fall on the other side under a different (equally
 # valid) rounding.  Every thresholding event records such cases instead of hiding them; parity runs assert there are none.
 NEAR_THRESHOLD_BAND = 1e-4
+# Coefficients are RECORDED within this wider band: an iterative fit ends inside its optimiser's stopping ball (L-BFGS
+# trainer: parameter update < 1e-3, train.py:643, 705), so two runs that differ in the last bit of a closure can differ
+# by that much in a coefficient at a thresholding event -- ``near_threshold_within(1e-3)`` is the list that explains a
+# mask flip there; ``near_threshold`` is the BASELINE.md section 3 list (1e-4).
+NEAR_THRESHOLD_RECORD_BAND = 1e-3
 
 
 def near_threshold_cases(xi, mask, threshold, band=NEAR_THRESHOLD_BAND):
@@ -168,6 +173,7 @@ class SINDyRegression(nn.Module):
         self.mask = torch.ones_like(self.Xi, device=device)
         self._gram_cache = None
         self._near = []                   # one dict per near-threshold coefficient met at a thresholding event
+        self._near_wide = []              # ... recorded within NEAR_THRESHOLD_RECORD_BAND (see near_threshold_within)
         self._near_pending = []           # device-side events not yet looked at (no host sync inside the solve loops)
 
     # ------------------------------------------------------------------ evaluation
@@ -245,8 +251,8 @@ class SINDyRegression(nn.Module):
             return
         xi = xi.detach().cpu().numpy() if torch.is_tensor(xi) else xi
         mask = mask.detach().cpu().numpy() if torch.is_tensor(mask) else mask
-        for i, k, v in near_threshold_cases(xi, mask, threshold):
-            self._near.append({'where': where, 'threshold': float(threshold), 'index': (i, k), 'abs_coef': v})
+        for i, k, v in near_threshold_cases(xi, mask, threshold, band=NEAR_THRESHOLD_RECORD_BAND):
+            self._near_wide.append({'where': where, 'threshold': float(threshold), 'index': (i, k), 'abs_coef': v})
 
     def _flush_near(self):
         pending, self._near_pending = self._near_pending, []
@@ -257,8 +263,12 @@ class SINDyRegression(nn.Module):
     def near_threshold(self):
         """[{'where', 'threshold', 'index': (row, col), 'abs_coef'}] for every coefficient that sat within 1e-4 of the
         threshold at a thresholding event."""
+        return self.near_threshold_within(NEAR_THRESHOLD_BAND)
+
+    def near_threshold_within(self, band):
+        """The same record for a wider band (at most NEAR_THRESHOLD_RECORD_BAND = 1e-3, the L-BFGS trainer's stopping ball)."""
         self._flush_near()
-        return self._near
+        return [e for e in self._near + self._near_wide if abs(e['abs_coef'] - e['threshold']) < band]
 
     def set_threshold(self, threshold):                                   # sindy.py:192-194 (strict >)
         self.Xi = self.get_Xi() if self.constraint else self.Xi

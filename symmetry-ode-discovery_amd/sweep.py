@@ -317,7 +317,9 @@ class BatchedLBFGS:
         loss, g = closure(self.P)
         self._loss.copy_(loss)
         self._g.copy_(g)
-        act = g.abs().amax(dim=1) > self.tol_g                              # optimality test
+        # optimality test in torch's sense (`if flat_grad.abs().max() <= tolerance_grad: return`): a NaN gradient does NOT
+        # stop the step -- the parameters go to NaN and the trainer's NaN guard ends the run (train.py:697)
+        act = ~(g.abs().amax(dim=1) <= self.tol_g)
         if frozen is not None:
             act = act & ~frozen
         self._act.copy_(act)
@@ -398,6 +400,36 @@ class SeedSweepLBFGS:
         r = c.Q.shape[1]
         return (A[:, :r] - B[:, :r]).norm(dim=1) + (A[:, r:] - B[:, r:]).norm(dim=1)
 
+    def _native_ok(self, P0):
+        """The device-resident trainer (device_lbfgs.DeviceTrainer: optimiser AND epoch logic as kernels of the library, no
+        stock torch op between the epochs) serves every GPU fit; the tensor-op form below is its restatement for CPU /
+        gloo test doubles and ``SYMODE_LBFGS_FUSED=0``."""
+        c = self.c
+        eng = getattr(c, 'engine', None)
+        return bool(P0.is_cuda and eng is not None and hasattr(getattr(eng, 'lib', None), 'symode_trainer_run')
+                    and os.environ.get('SYMODE_LBFGS_FUSED', '1') == '1' and os.environ.get('SYMODE_LBFGS_MERGED', '1') == '1'
+                    and P0.shape[1] <= 256 and c.d * c.p <= 256 and getattr(c, 'n_chunks', 1) == 1)
+
+    def _fit_native(self, P0, num_epochs, mask0, on_epoch):
+        from .device_lbfgs import DeviceTrainer
+        c = self.c
+        tr = DeviceTrainer(c.x, c.dx, c.order, c.flags, Q=c.Q, use_kron_product=c.use_kron, allow_constant=c.allow_constant,
+                           reversed_sym=c.sym, lr=self.lr, threshold=self.threshold, st_freq=self.st_freq, w_x=self.w_x,
+                           w_reg=self.w_reg if self.reg_type == 'l1' else 0.0, l1=True, tol=self.tol, inv_count=c.inv_count,
+                           engine=c.engine, group=(c.group or dist.group.WORLD) if c.distributed else None,
+                           detail=on_epoch is not None and c.S <= 64)
+        self.trainer = tr
+        cb = None
+        if on_epoch is not None:
+            dev = P0.device
+
+            def cb(epoch, rec):                              # the tensor-op form's callback signature
+                done = torch.from_numpy((rec['code'] == 3) | (rec['code'] == 4) | (rec['code'] == -1))
+                return on_epoch(epoch, tr.field('params'), tr.field('mask').view(c.S, c.d, c.p), done.to(dev))
+        out = tr.fit(P0, num_epochs, mask0=mask0, on_epoch=cb)
+        self.mask = out['mask'].to(P0.device)
+        return {k: v.to(P0.device) for k, v in out.items()}
+
     @torch.no_grad()
     def fit(self, P0, num_epochs, mask0=None, on_epoch=None):
         """P0 (S, n): initial flat parameters per seed ([Xi] or [beta | const]).
@@ -405,6 +437,8 @@ class SeedSweepLBFGS:
         caller that reads them synchronises; returning True ends the fit) -- per-epoch logs / interval checkpoints.
         Returns dict(Xi, mask, params, epochs (S,), finished (S,), nan (S,))."""
         c = self.c
+        if self._native_ok(P0):
+            return self._fit_native(P0, num_epochs, mask0, on_epoch)
         P = P0.clone().contiguous()
         S = P.shape[0]
         self.mask = torch.ones(S, c.d, c.p, device=P.device) if mask0 is None else mask0.clone()

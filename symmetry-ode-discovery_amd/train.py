@@ -773,80 +773,91 @@ def _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, thre
 
 
 def _train_on_device(regressor, x, dx, autoencoder, generator, num_epochs, lr_sindy, st_freq, threshold, w_sindy_x,
-                     sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq, log_interval=0, save_interval=0):
-    """The non-latent L-BFGS fit with NOTHING on the host between epochs: the one-seed case of sweep.SeedSweepLBFGS --
-    closure kernel + one optimiser launch per inner iteration (symode_lbfgs_accept_update), the per-epoch logic of
-    train.py:692-725 (NaN guard, update-norm test, thresholding, optimiser reset, final convergence) as mask arithmetic
-    on device tensors, one host sync every fourth epoch.  Same update rules and events as the default path statement
-    by statement, but torch's own optimiser it is not: on the recorded runs it lands on the same masks (tests).  Log lines
-    and interval checkpoints are produced at ``log_interval`` / ``save_interval`` (each one synchronises); the per-epoch
-    wandb record and the "test" log of the default path are not.
-    7.6 ms against 48 ms for the 125 000-point problem (profiles/r02_sweep_lbfgs.txt)."""
-    from .batched import BatchedClosure
-    from .sweep import SeedSweepLBFGS
+                     sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq, log_interval=0, save_interval=0,
+                     test_log=None, group=None):
+    """The non-latent L-BFGS fit with NOTHING on the host between two epochs (device_lbfgs.DeviceTrainer): closure kernel +
+    ONE optimiser launch per inner iteration, the per-epoch logic of train.py:697-725 as one more launch, and a record per
+    epoch in pinned memory from which this function produces what the reference produces per epoch -- the convergence /
+    thresholding / NaN messages, the loss line, the "test" line (train.py:739-751), the equations, the wandb record and the
+    interval checkpoints -- in the reference's order.  The record holds the LAST closure evaluation's terms (what the
+    reference's ``losses`` dict holds when the epoch ends) and, for the "test" line, the closure re-evaluated at the
+    epoch's final coefficients and mask.  ``group``: x, dx are this rank's point shard."""
+    from .device_lbfgs import EVENT_FINAL, EVENT_NAN, EVENT_THRESHOLD_CONVERGED, EVENT_THRESHOLD_PERIOD, DeviceTrainer
+    d = x.shape[-1]
     rev = None
     if w_sym_reg > 0.0:
         from .model_utils import precompute_symmreg_r
         gx, jgx = precompute_symmreg_r(x, autoencoder, generator, scale=0.01)
-        rev = (torch.stack(gx)[None].contiguous(), torch.stack(jgx)[None].contiguous(), w_sym_reg / w_sindy_x)
-    xs, dxs = x.reshape(1, -1, x.shape[-1]).contiguous(), dx.reshape(1, -1, x.shape[-1]).contiguous()
-    if rev is not None:
-        rev = (rev[0].reshape(1, rev[0].shape[1], -1, x.shape[-1]), rev[1].reshape(1, rev[1].shape[1], -1, x.shape[-1], x.shape[-1]), rev[2])
-    clos = BatchedClosure(xs, dxs, regressor.poly_order, regressor.include_sine, regressor.include_exp,
-                          Q=regressor.Q if regressor.constraint else None,
-                          use_kron_product=getattr(regressor, 'use_kron_product', True),
-                          allow_constant=getattr(regressor, 'allow_constant', True), engine=regressor.engine, reversed_sym=rev)
+        gx, jgx = torch.stack(gx), torch.stack(jgx)
+        rev = (gx.reshape(1, gx.shape[0], -1, d).contiguous(), jgx.reshape(1, jgx.shape[0], -1, d, d).contiguous(),
+               w_sym_reg / w_sindy_x)
+    xs, dxs = x.reshape(1, -1, d).contiguous(), dx.reshape(1, -1, d).contiguous()
     with torch.no_grad():
         if regressor.constraint:
-            P0 = torch.cat([regressor.beta.detach().reshape(-1), regressor.const.detach().reshape(-1)])[None]
+            P0 = torch.cat([regressor.beta.detach().reshape(-1), regressor.const.detach().reshape(-1)]).cpu()[None]
         else:
-            P0 = regressor.Xi.detach().reshape(1, -1)
-    sweep = SeedSweepLBFGS(clos, lr_sindy, threshold, st_freq, w_sindy_x=w_sindy_x, sindy_reg_type=sindy_reg_type,
-                           w_sindy_reg=w_sindy_reg)
-    def adopt(P, mask):                                    # the sweep's state into the regressor (device copies)
+            P0 = regressor.Xi.detach().reshape(1, -1).cpu()
+        mask_before = regressor.mask.detach().cpu().numpy().copy()
+    tr = DeviceTrainer(xs, dxs, regressor.poly_order, regressor.flags, Q=regressor.Q if regressor.constraint else None,
+                       use_kron_product=getattr(regressor, 'use_kron_product', True),
+                       allow_constant=getattr(regressor, 'allow_constant', True), reversed_sym=rev, lr=lr_sindy,
+                       threshold=threshold, st_freq=st_freq, w_x=w_sindy_x, w_reg=w_sindy_reg if sindy_reg_type == 'l1' else 0.0,
+                       l1=sindy_reg_type == 'l1', engine=regressor.engine, detail=True, group=group)
+
+    def adopt(params, mask):                               # a host state into the regressor (two small uploads)
         with torch.no_grad():
+            params = torch.as_tensor(params)
             if regressor.constraint:
                 r = regressor.Q.shape[1]
-                regressor.beta.data.copy_(P[:r].view_as(regressor.beta))
-                regressor.const.data.copy_(P[r:].view_as(regressor.const))
+                regressor.beta.data.copy_(params[:r].view_as(regressor.beta))
+                regressor.const.data.copy_(params[r:].view_as(regressor.const))
             else:
-                regressor.Xi.data.copy_(P.view_as(regressor.Xi))
-            regressor.mask.data = mask.clone()
+                regressor.Xi.data.copy_(params.view_as(regressor.Xi))
+            regressor.mask.copy_(torch.as_tensor(mask).view_as(regressor.mask))
 
-    def on_epoch(epoch, P, mask, done):
+    state = {'mask_before': mask_before}
+
+    def on_epoch(epoch, rec):
+        code = int(rec['code'][0])
+        if code == EVENT_NAN:                                                          # train.py:697-699
+            print(f'NaN encountered at iteration {epoch}; exit training.')
+            return True
+        losses['loss_sindy_x'] = float(rec['mse'][0])
+        if rev is not None:
+            losses['loss_sym_reg'] = float(rec['sym'][0])
+        if sindy_reg_type == 'l1':
+            losses['loss_sindy_reg'] = float(rec['l1'][0])
+        wandb_log = dict(losses)
+        if code == EVENT_FINAL:                                                        # train.py:709-714
+            print(f'Final convergence reached at iteration {epoch}; exit training.')
+            adopt(rec['params'][0], rec['mask'][0])
+            _save(regressor, save_dir, f'regressor_{epoch}.pt')
+            return True
+        if code in (EVENT_THRESHOLD_CONVERGED, EVENT_THRESHOLD_PERIOD):
+            regressor.note_near_threshold(rec['xi'][0], state['mask_before'], threshold, 'set_threshold (device trainer)')
+            print('Convergence reached at iteration {}; apply parameter thresholding and reset optimizer.'.format(epoch)
+                  if code == EVENT_THRESHOLD_CONVERGED else
+                  'Max number of LBFGS iterations reached; apply parameter thresholding and reset optimizer.')
+        state['mask_before'] = rec['mask'][0].copy()
         log = log_interval > 0 and (epoch + 1) % log_interval == 0
         save = save_interval > 0 and (epoch + 1) % save_interval == 0
         if log or save:
-            adopt(P[0], mask[0])
-            if log:
-                with torch.no_grad():
-                    cur, _ = clos.loss_grad_xi(sweep._xi(P), mask)
-                key = 'loss_sindy_x' if rev is None else 'loss_sindy_x_plus_sym_reg'
-                print(f'Epoch {epoch}, {key}: {float(cur[0]):.4f}')
-                if print_eq:
-                    regressor.print()
-            if save:
-                _save(regressor, save_dir, f'regressor_{epoch}.pt')
-            return bool(done.all())                        # (already synchronised: stop right at the final epoch)
+            adopt(rec['params'][0], rec['mask'][0])
+        if log:
+            print(', '.join([f'Epoch {epoch}'] + [f'{k}: {v:.4f}' for k, v in losses.items()]))
+            if test_log is not None:
+                wandb_log.update(test_log(epoch, float(rec['test'][0])))
+            if print_eq:
+                regressor.print()
+        wandb.log(wandb_log)
+        if save:
+            _save(regressor, save_dir, f'regressor_{epoch}.pt')
         return False
 
-    out = sweep.fit(P0.float().contiguous(), num_epochs, mask0=regressor.mask[None].clone(),
-                    on_epoch=on_epoch if (log_interval > 0 or save_interval > 0) else None)
+    out = tr.fit(P0, num_epochs, mask0=torch.from_numpy(mask_before)[None], on_epoch=on_epoch,
+                 test_eval=test_log is not None and log_interval > 0)
     adopt(out['params'][0], out['mask'][0])
-    with torch.no_grad():
-        final, _ = clos.loss_grad_xi(out['Xi'], regressor.mask[None])          # mse, or mse + (w_sym / w_x) * regulariser
-        losses['loss_sindy_x' if rev is None else 'loss_sindy_x_plus_sym_reg'] = final[0].clone()
-    epochs = int(out['epochs'][0])
-    if bool(out['nan'][0]):
-        print(f'NaN encountered at iteration {epochs - 1}; exit training.')
-    elif bool(out['finished'][0]):
-        print(f'Final convergence reached at iteration {epochs - 1}; exit training.')
-    n_near = int(out['near_threshold'][0])
-    if n_near:                                       # met at a thresholding event (counted on the device, values not kept)
-        regressor._near.append({'where': 'device_lbfgs', 'threshold': float(threshold), 'count': n_near})
-    if print_eq:
-        regressor.print()
-    _save(regressor, save_dir, f'regressor_{max(epochs - 1, 0)}.pt')
+    return out
 
 
 def train_SIGED_lbfgs(
@@ -922,11 +933,14 @@ def train_SIGED_lbfgs(
     frozen = not any(p.requires_grad for m in (autoencoder, generator) for p in m.parameters())
     eligible = (x.is_cuda and not use_latent and kwargs.get('host_lbfgs', True)
                 and (w_sym_reg <= 0.0 or (sym_reg_type == 'r' and frozen)))
-    if eligible and kwargs.get('device_lbfgs', False) and w_sindy_x > 0 and sindy_reg_type in ('l1', 'none'):
-        # opt-in (--device_lbfgs): optimiser AND per-epoch logic on the device -- see _train_on_device
-        return _train_on_device(regressor, x, dx, autoencoder, generator, num_epochs, lr_sindy, st_freq, threshold, w_sindy_x,
-                                sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq, log_interval, save_interval)
-    if eligible:
+    # DEFAULT for every closure made only of fused kernels: optimiser AND per-epoch logic on the device (_train_on_device).
+    # torch's own optimiser on host-resident variables (the reference's torch.optim.LBFGS, operation for operation) stays
+    # available: --torch_lbfgs / torch_lbfgs=True / SYMODE_TORCH_OPTIM=1.
+    on_device = (eligible and not kwargs.get('torch_lbfgs', False) and not kwargs.get('numpy_lbfgs', False)
+                 and os.environ.get('SYMODE_TORCH_OPTIM', '0') != '1' and w_sindy_x > 0 and sindy_reg_type in ('l1', 'none')
+                 and hasattr(getattr(regressor.engine, 'lib', None), 'symode_trainer_run')
+                 and regressor.mask.numel() <= 256)
+    if eligible and not on_device:
         rev = None
         if w_sym_reg > 0.0:
             from .model_utils import precompute_symmreg_r
@@ -980,7 +994,8 @@ def train_SIGED_lbfgs(
             loss.backward()
             return loss
 
-    def test_log(epoch):
+    def test_log(epoch, value=None):
+        # ``value``: the closure at the epoch's final coefficients and mask, already evaluated by the device trainer.
         # The reference evaluates the TRAIN batch once per element of test_loader here (:739-751): the same number, n times
         # (lv: n = 780 at every logged epoch -- 45 % of the wall time of lv/noise99_eq_isymreg.cfg).  It is evaluated once
         # and accumulated n times in the reference's float arithmetic, so the logged mean is the reference's bit for bit.
@@ -991,6 +1006,8 @@ def train_SIGED_lbfgs(
                 if use_latent:
                     z, _ = autoencoder(x)
                     key, v = 'test_loss_sindy_z', regressor.mse_loss(z, autoencoder.compute_dz(x, dx)).item()
+                elif value is not None:
+                    key, v = 'test_loss_sindy_x', value
                 else:
                     key, v = 'test_loss_sindy_x', regressor.mse_loss(x, dx).item()
             for _ in range(n):
@@ -1001,13 +1018,18 @@ def train_SIGED_lbfgs(
 
     if shadow is not None and shadow.flat is not None:
         closure = closure_np
-    if shadow is None and x.is_cuda and kwargs.get('host_lbfgs', True):
+    if shadow is None and not on_device and x.is_cuda and kwargs.get('host_lbfgs', True):
         # autograd closures (i / f regulariser through the stock autoencoder, latent branch): the closure stays on the
         # device, the optimiser's variables move to the host
         shadow = _HostParams(regressor)
         closure = shadow.wrap(closure)
-    _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, threshold, log_interval, save_interval,
-                 save_dir, print_eq, on_log=test_log, shadow=shadow)
+    if on_device:
+        _train_on_device(regressor, x, dx, autoencoder, generator, num_epochs, lr_sindy, st_freq, threshold, w_sindy_x,
+                         sindy_reg_type, w_sindy_reg, w_sym_reg, losses, save_dir, print_eq, log_interval, save_interval,
+                         test_log=test_log, group=kwargs.get('group'))
+    else:
+        _lbfgs_phase(regressor, closure, losses, num_epochs, lr_sindy, st_freq, threshold, log_interval, save_interval,
+                     save_dir, print_eq, on_log=test_log, shadow=shadow)
 
     # (Optional) Phase 2: distill equation from latent to data space                   # train.py:768-852
     if not distill_latent:

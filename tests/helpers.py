@@ -112,7 +112,7 @@ def f11_case(g, tag):
     c = dict(tag=tag, d=d, order=order, constrain_constant=bool(cc), lr=lr, st_freq=int(st_freq), thr=thr, epochs=int(epochs),
              x=t(g[f"{tag}_x"]), dx=t(g[f"{tag}_dx"]), mask_final=g[f"{tag}_mask_final"], Xi_final=g[f"{tag}_Xi_final"],
              loss_hist=g[f"{tag}_loss_hist"], thr_epoch=g[f"{tag}_thr_epoch"], thr_Xi=g[f"{tag}_thr_Xi"],
-             thr_mask_before=g[f"{tag}_thr_mask_before"], L=None)
+             thr_mask_before=g[f"{tag}_thr_mask_before"], L=None, trace_Xi=t(g[f"{tag}_trace_Xi"]), trace_mask=t(g[f"{tag}_trace_mask"]))
     if f"{tag}_L" in g.files:
         c.update(L=t(g[f"{tag}_L"]), Q=t(g[f"{tag}_Q"]), beta0=t(g[f"{tag}_init_beta"]), const0=t(g[f"{tag}_init_const"]),
                  use_kron=bool(g[f"{tag}_use_kron"]))
@@ -124,6 +124,15 @@ def f11_case(g, tag):
         hit = (np.abs(np.abs(Xi) - np.float32(thr)) < 1e-4) & (m > 0)
         near += [(int(i), int(k)) for i, k in zip(*np.nonzero(hit))]
     c["near"] = near
+    wide = []                                        # ... within the trainer's stopping ball (1e-3, train.py:643)
+    for Xi, m in zip(c["thr_Xi"], c["thr_mask_before"]):
+        hit = (np.abs(np.abs(Xi) - np.float32(thr)) < 1e-3) & (m > 0)
+        wide += [(int(i), int(k)) for i, k in zip(*np.nonzero(hit))]
+    c["near_wide"] = wide
+    # the reference itself from 12 starts one unit in the last place away (tools/gen_golden.py::f11_lbfgs_noisy)
+    c["ulp_masks"], c["ulp_logged_epochs"] = g[f"{tag}_ulp_masks"], g[f"{tag}_ulp_logged_epochs"]
+    c["ulp_thr_epoch"], c["ulp_last_loss"], c["ulp_first_loss"] = g[f"{tag}_ulp_thr_epoch"], g[f"{tag}_ulp_last_loss"], g[f"{tag}_ulp_first_loss"]
+    c["unstable"] = [(int(i), int(k)) for i, k in np.argwhere((c["ulp_masks"] != c["mask_final"][None]).any(axis=0))]
     return c
 
 
@@ -141,3 +150,23 @@ def f11_oracle_regressor(O, c, cls=None, own_Q=False):
     else:
         reg.Q = c["Q"]
     return reg
+
+
+def compiled(d, order, flags=0):
+    """Is library (d, order, flags) in the built libsymode_hip.so?  (d = 4 only with `make ALL=1`.)  No GPU needed."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from symode_amd.engine import load_library
+    global _LIB
+    try:
+        _LIB
+    except NameError:
+        _LIB = load_library()
+    return _LIB.symode_lib_size(int(d), int(order), int(flags)) >= 0
+
+
+def only_compiled(cases):
+    """Filter a parametrize list whose entries start with (d, order, ...)."""
+    return [c for c in cases if compiled(c[0], c[1])]

@@ -37,6 +37,7 @@ def main():
               autoencoder=ident, generator=ident, regressor_dst=None, use_latent=False, distill_latent=False, lr_sindy=0.1,
               w_sindy_z=0.0, w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="i", w_sym_reg=0.0,
               st_freq=50, threshold=0.05, int_t=0.1, int_dt=0.01, print_eq=False)
+    # torch's optimiser on device tensors / on host variables, the numpy restatement, and the default (device trainer)
     for host, npy, dev_k in ((False, False, False), (True, False, False), (True, True, False), (True, False, True)):
         for rep in range(2):                       # first run warms up
             r = symode_amd.SINDyRegression(2, a.order, False, False, threshold=0.05, device="cuda")
@@ -44,10 +45,10 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
-                symode_amd.train.train_SIGED_lbfgs(train_loader=[(x, dx)], device="cuda", regressor=r, host_lbfgs=host, numpy_lbfgs=npy, device_lbfgs=dev_k, **kw)
+                symode_amd.train.train_SIGED_lbfgs(train_loader=[(x, dx)], device="cuda", regressor=r, host_lbfgs=host, numpy_lbfgs=npy, torch_lbfgs=not dev_k, **kw)
             torch.cuda.synchronize()
             t_gpu = time.perf_counter() - t0
-        print(f"GPU train_SIGED_lbfgs host_lbfgs={host} numpy_lbfgs={npy} device_lbfgs={dev_k}: {t_gpu:.4f} s; mask rows {r.mask.int().cpu().numpy().tolist()}")
+        print(f"GPU train_SIGED_lbfgs host_lbfgs={host} numpy_lbfgs={npy} device_trainer(default)={dev_k}: {t_gpu:.4f} s; mask rows {r.mask.int().cpu().numpy().tolist()}")
     print(f"GPU train_SIGED_lbfgs: {t_gpu:.3f} s; mask\n{r.mask.int().cpu().numpy()}\nXi\n{np.round((r.Xi*r.mask).detach().cpu().numpy(), 4)}")
     if not a.skip_cpu:
         torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import sindy_oracle as O
-from tests.helpers import TinyAE, t
+from tests.helpers import TinyAE, only_compiled, t
 
 pytestmark = pytest.mark.gpu
 
@@ -58,7 +58,7 @@ def test_theta_golden_bit_exact(eng, golden):
     assert got[0].tolist() == [1, 2, 3, 4, 6, 9, 8, 12, 18, 27]
 
 
-@pytest.mark.parametrize("d,order", [(1, 5), (2, 4), (2, 5), (3, 4), (4, 3)])
+@pytest.mark.parametrize("d,order", only_compiled([(1, 5), (2, 4), (2, 5), (3, 4), (4, 3)]))
 def test_theta_high_order_vs_oracle(eng, d, order):
     """Orders 4-5 extend the reference ordering (parity unpinned by the reference itself)."""
     torch.manual_seed(d * 10 + order)
@@ -91,7 +91,7 @@ def test_forward_loss_grad_golden(eng, golden, tag):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 65, 255, 1023, 4097, 125000])
-@pytest.mark.parametrize("d,order,fl", [(2, 3, 0), (2, 5, 0), (1, 3, 1), (3, 2, 2), (4, 2, 0), (4, 3, 0), (3, 4, 1), (3, 3, 3), (4, 2, 3)])
+@pytest.mark.parametrize("d,order,fl", only_compiled([(2, 3, 0), (2, 5, 0), (1, 3, 1), (3, 2, 2), (4, 2, 0), (4, 3, 0), (3, 4, 1), (3, 3, 3), (4, 2, 3)]))
 def test_loss_grad_ragged_sizes_vs_oracle(eng, n, d, order, fl):
     torch.manual_seed(n + 7 * d + order)
     x, dx = torch.randn(n, d) * 0.8, torch.randn(n, d)
@@ -147,7 +147,7 @@ def test_loss_grad_batched_three_dimensional_states(eng, S, n):
         assert_close_scaled(grad[s].cpu().numpy(), wg.numpy(), 2e-5)
 
 
-@pytest.mark.parametrize("d,order,fl,S,n", [(4, 3, 0, 3, 5000), (3, 4, 0, 4, 4099), (4, 3, 2, 2, 777)])
+@pytest.mark.parametrize("d,order,fl,S,n", only_compiled([(4, 3, 0, 3, 5000), (3, 4, 0, 4, 4099), (4, 3, 2, 2, 777)]))
 def test_loss_grad_large_libraries_row_per_wave(eng, d, order, fl, S, n):
     """d*p > 64: the row-per-wave kernel (a workgroup = d waves over the same points, wave j owns row j of Xi), batched."""
     torch.manual_seed(S + n)
@@ -204,7 +204,7 @@ def test_odeint_golden(eng, golden, tag):
 
 
 @pytest.mark.parametrize("n", [1, 255, 256, 1027, 4096, 125000])
-@pytest.mark.parametrize("d,order,fl", [(3, 3, 0), (3, 2, 3), (1, 4, 0), (2, 3, 0), (4, 2, 0)])
+@pytest.mark.parametrize("d,order,fl", only_compiled([(3, 3, 0), (3, 2, 3), (1, 4, 0), (2, 3, 0), (4, 2, 0)]))
 def test_forward_and_odeint_chunked_streams_vs_oracle(eng, n, d, order, fl):
     """Streaming map kernels at ragged and full sizes for every chunk layout (d = 1: 4 points per 16 bytes, d = 2: 2, d = 3:
     coalesced 192-vector tiles redistributed through LDS for whole waves / strided loads for ragged ones, d = 4: 1)."""
@@ -221,7 +221,7 @@ def test_forward_and_odeint_chunked_streams_vs_oracle(eng, n, d, order, fl):
     assert np.allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("d,order,fl,method", [(2, 3, 0, "rk4"), (2, 2, 2, "rk4"), (2, 5, 0, "euler"), (3, 2, 1, "rk4"), (1, 3, 0, "euler"), (4, 2, 0, "rk4")])
+@pytest.mark.parametrize("d,order,fl,method", only_compiled([(2, 3, 0, "rk4"), (2, 2, 2, "rk4"), (2, 5, 0, "euler"), (3, 2, 1, "rk4"), (1, 3, 0, "euler"), (4, 2, 0, "rk4")]))
 def test_odeint_full_trajectory_vs_oracle_steps(eng, d, order, fl, method):
     """symode_odeint_traj: the state after EVERY step equals the oracle's chained fp32 steps (odeint(..., full_traj=True));
     its last row is what symode_odeint returns."""
@@ -245,7 +245,7 @@ def test_odeint_full_trajectory_vs_oracle_steps(eng, d, order, fl, method):
 
 
 # ------------------------------------------------------------------------------------ gram
-@pytest.mark.parametrize("d,order,fl", [(2, 2, 0), (2, 3, 0), (2, 5, 0), (2, 2, 2), (3, 3, 0), (1, 4, 3), (4, 3, 0), (3, 4, 1)])
+@pytest.mark.parametrize("d,order,fl", only_compiled([(2, 2, 0), (2, 3, 0), (2, 5, 0), (2, 2, 2), (3, 3, 0), (1, 4, 3), (4, 3, 0), (3, 4, 1)]))
 @pytest.mark.parametrize("n", [1, 63, 256, 257, 5000])
 def test_aug_gram_vs_fp64_host(eng, d, order, fl, n):
     torch.manual_seed(n + order)
@@ -495,8 +495,8 @@ def test_zero_copy_closure_matches_copy_path(eng):
 
 
 # ------------------------------------------------------------- batched reversed symmetry regulariser
-@pytest.mark.parametrize("S,n,n_g,d,order,fl", [(1, 20000, 1, 2, 2, 2), (3, 4096, 2, 2, 3, 0), (2, 1001, 1, 2, 5, 0), (1, 777, 3, 3, 2, 1),
-                                                (4, 512, 1, 1, 4, 0), (2, 300, 2, 4, 2, 0)])
+@pytest.mark.parametrize("S,n,n_g,d,order,fl", [c for c in [(1, 20000, 1, 2, 2, 2), (3, 4096, 2, 2, 3, 0), (2, 1001, 1, 2, 5, 0), (1, 777, 3, 3, 2, 1),
+                                                            (4, 512, 1, 1, 4, 0), (2, 300, 2, 4, 2, 0)] if only_compiled([c[3:5]])])
 def test_symreg_reversed_batched_vs_oracle(eng, S, n, n_g, d, order, fl):
     """symode_symreg_reversed_batched (16-byte non-temporal chunk loads of x, g(x), J_g; ragged tails and unaligned slabs
     fall back to per-point loads) against the oracle's model_utils.py:166-168 with the explicit matvec."""
@@ -547,8 +547,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert "x read once" in rec["roofline"]["kernel"] and rec["roofline"]["bytes_per_point"] == 40
 
 
-@pytest.mark.parametrize("d,order,fl,K,n", [(2, 2, 2, 10, 20000), (2, 3, 0, 3, 4097), (3, 2, 0, 5, 3001), (1, 4, 1, 16, 1000), (2, 5, 0, 20, 2500),
-                                            (4, 2, 0, 4, 999)])
+@pytest.mark.parametrize("d,order,fl,K,n", only_compiled([(2, 2, 2, 10, 20000), (2, 3, 0, 3, 4097), (3, 2, 0, 5, 3001), (1, 4, 1, 16, 1000),
+                                                          (2, 5, 0, 20, 2500), (4, 2, 0, 4, 999)]))
 def test_euler_reverse_sweep_state_stack_equals_recompute(eng, d, order, fl, K, n):
     """euler_jvp_vjp keeps the K step states in an LDS column (K <= 16 at d = 2) or recomputes them (larger K,
     SYMODE_EULER_STACK=0): the same adjoints either way, and both match torch autograd through the stepwise flow."""
@@ -581,8 +581,8 @@ def test_euler_reverse_sweep_state_stack_equals_recompute(eng, d, order, fl, K, 
     assert_close_scaled(to.cpu(), ts.detach(), 1e-5, "euler_jvp t_K")
 
 
-@pytest.mark.parametrize("T,K,d,order,fl", [(2000, 50, 2, 3, 0), (777, 50, 2, 2, 2), (8000, 50, 2, 5, 0), (300, 7, 3, 2, 1), (64, 128, 1, 4, 0),
-                                            (1000, 20, 4, 3, 0)])
+@pytest.mark.parametrize("T,K,d,order,fl", [c for c in [(2000, 50, 2, 3, 0), (777, 50, 2, 2, 2), (8000, 50, 2, 5, 0), (300, 7, 3, 2, 1),
+                                                        (64, 128, 1, 4, 0), (1000, 20, 4, 3, 0)] if only_compiled([c[2:4]])])
 def test_weak_gram_fused_contraction(eng, T, K, d, order, fl):
     """symode_weak_gram: G = V Theta(x), b = -V' x accumulated by the fp64 matrix cores vs an fp64 host product of the
     same fp32 library and test functions (exact products, fp64 sums: 1e-12 like the Gram)."""
@@ -598,9 +598,10 @@ def test_weak_gram_fused_contraction(eng, T, K, d, order, fl):
     assert torch.allclose(b.cpu(), want_b, rtol=1e-12, atol=1e-12 * want_b.abs().max().item())
 
 
-@pytest.mark.parametrize("S,n,d,order,fl", [(1, 125000, 2, 3, 0), (5, 4099, 2, 2, 2), (3, 1000, 2, 2, 0), (2, 777, 1, 5, 2), (1, 3000, 3, 1, 0),
-                                            (2, 5000, 2, 5, 0), (2, 3001, 2, 4, 0), (1, 2050, 2, 4, 3), (3, 999, 3, 2, 0),
-                                            (2, 1500, 4, 2, 0), (1, 70001, 3, 3, 0), (1, 8, 2, 5, 0)])
+@pytest.mark.parametrize("S,n,d,order,fl", [c for c in [(1, 125000, 2, 3, 0), (5, 4099, 2, 2, 2), (3, 1000, 2, 2, 0), (2, 777, 1, 5, 2),
+                                                        (1, 3000, 3, 1, 0), (2, 5000, 2, 5, 0), (2, 3001, 2, 4, 0), (1, 2050, 2, 4, 3),
+                                                        (3, 999, 3, 2, 0), (2, 1500, 4, 2, 0), (1, 70001, 3, 3, 0), (1, 8, 2, 5, 0)]
+                                            if only_compiled([c[2:4]])])
 def test_gram_vector_pipe_and_matrix_core_forms_agree(eng, S, n, d, order, fl):
     """Small libraries (F = p + d <= 12) take the fp64 vector-pipe Gram (one fma per distinct entry), 12 < F <= 24 its split
     form (the triangle in 2, 3 or 4 runs over sibling workgroups: F = 13, 17, 19, 21, 23 here), larger ones and

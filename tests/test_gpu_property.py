@@ -12,7 +12,9 @@ from oracle import sindy_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-LIBS = [(d, o) for d in (1, 2) for o in range(1, 6)] + [(3, o) for o in range(1, 5)] + [(4, o) for o in range(1, 4)]
+from tests.helpers import only_compiled
+
+LIBS = only_compiled([(d, o) for d in (1, 2) for o in range(1, 6)] + [(3, o) for o in range(1, 5)] + [(4, o) for o in range(1, 4)])
 
 
 @pytest.fixture(scope="module")

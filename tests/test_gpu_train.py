@@ -35,9 +35,9 @@ def _regressor(S, g, tag, d, order, thr):
 @pytest.mark.parametrize("mode", ["host_numpy", "host_torch", "device", "device_kernels"])
 @pytest.mark.parametrize("tag", ["dosc_sindy", "dosc_esindy", "selkov_sindy"])
 def test_lbfgs_trainer_on_gpu_matches_reference_run(S, golden, tag, mode, tmp_path, monkeypatch):
-    """The reference's three recorded runs through every optimiser placement: torch.optim.LBFGS on host variables
-    (default) / on device tensors, the numpy restatement, and ``device_lbfgs=True`` (optimiser + epoch logic as device
-    kernels, one launch per inner iteration beside the closure kernel)."""
+    """The reference's three recorded runs through every optimiser placement: the DEFAULT (optimiser + epoch logic as
+    device kernels: one launch per inner iteration beside the closure kernel, one per epoch), torch.optim.LBFGS's own
+    operations on host variables (``torch_lbfgs=True``) / on device tensors, and the numpy restatement."""
     host_lbfgs, numpy_lbfgs = mode != "device", mode == "host_numpy"
     if numpy_lbfgs and tag == "selkov_sindy":
         pytest.skip("opt-in numpy L-BFGS: chaotic trajectory on the ill-conditioned selkov library (see train.py)")
@@ -53,9 +53,9 @@ def test_lbfgs_trainer_on_gpu_matches_reference_run(S, golden, tag, mode, tmp_pa
                               regressor=r, regressor_dst=None, use_latent=False, distill_latent=False, lr_sindy=float(lr),
                               w_sindy_z=0.0, w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="i",
                               w_sym_reg=0.0, st_freq=int(st_freq), threshold=float(thr), int_t=0.1, int_dt=0.01, print_eq=False,
-                              host_lbfgs=host_lbfgs, numpy_lbfgs=numpy_lbfgs, device_lbfgs=mode == "device_kernels")
+                              host_lbfgs=host_lbfgs, numpy_lbfgs=numpy_lbfgs, torch_lbfgs=mode != "device_kernels")
     assert np.array_equal(r.mask.cpu().numpy(), g[f"{tag}_mask_final"])            # identical sparsity mask
-    if mode == "device_kernels":
+    if mode == "device_kernels":                # the reference saves on final convergence (train.py:709-714)
         import os
         assert any(f.startswith("regressor_") for f in os.listdir("saved_models/t"))
     want = g[f"{tag}_Xi_final"]
@@ -190,27 +190,49 @@ def test_trainer_with_symmetry_regulariser_runs_and_matches_oracle_closure(S, go
 
 
 def test_device_lbfgs_path_writes_logs_and_interval_checkpoints(S, golden, tmp_path, monkeypatch, capsys):
-    """``device_lbfgs=True`` with the reference configs' log / save intervals: an 'Epoch k, loss_sindy_x' line per logged
-    epoch, ``regressor_<epoch>.pt`` at the save interval and at the end, and the same final mask as without them."""
+    """The default path (optimiser + epoch logic on the device) with the reference configs' log / save intervals produces
+    what the reference produces per epoch, from its per-epoch records: an 'Epoch k, loss_sindy_x' line and a "test" line
+    (train.py:739-751) per logged epoch, one wandb record per epoch with the reference's keys, ``regressor_<epoch>.pt`` at the
+    save interval and on final convergence (train.py:709-714) -- and nothing after a run that only ran out of epochs;
+    the same final mask with and without the logging; the same records as torch's own optimiser writes on the same
+    problem (first epoch: 20 iterations from the same start)."""
     monkeypatch.chdir(tmp_path)
     g = golden("f4_lbfgs")
     x, dx = t(g["dosc_sindy_x"]), t(g["dosc_sindy_dx"])
     ident = torch.nn.Identity()
-    masks = []
-    for log, save in ((1, 2), (10 ** 9, 10 ** 9)):
+    masks, records = [], {}
+    for name, log, save, torch_opt in (("dl1", 1, 2, False), ("quiet", 10 ** 9, 10 ** 9, False), ("torch", 1, 2, True)):
         r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV)
         r.Xi.data = t(g["dosc_sindy_init_Xi"]).to(DEV)
+        logged = []
+        monkeypatch.setattr(S.train.wandb, "log", lambda dct, *a, _l=logged, **k: _l.append(dict(dct)), raising=False)
         S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ident, generator=ident, regressor=r,
-                                  **_train_kwargs(num_epochs=60, lr_sindy=0.1, threshold=0.05, st_freq=50, device_lbfgs=True,
-                                                  log_interval=log, save_interval=save, save_dir=f"dl{log}"))
+                                  **_train_kwargs(num_epochs=60, lr_sindy=0.1, threshold=0.05, st_freq=50, torch_lbfgs=torch_opt,
+                                                  log_interval=log, save_interval=save, save_dir=name, test_loader=[(x, dx)] * 3))
         masks.append(r.mask.cpu().numpy())
-    out = capsys.readouterr().out
+        records[name] = logged
+        if name == "dl1":
+            out = capsys.readouterr().out
     assert "Epoch 0, loss_sindy_x:" in out and "Epoch 1, loss_sindy_x:" in out and "Final convergence reached" in out
+    assert out.count("test_loss_sindy_x") == len(records["dl1"])
     files = sorted(os.listdir("saved_models/dl1"))
     assert "regressor_1.pt" in files and "regressor_3.pt" in files and len(files) >= 3
+    assert sorted(os.listdir("saved_models/torch")) == files                       # the same checkpoints as the host path
     state = torch.load(f"saved_models/dl1/{files[-1]}", weights_only=True)
     assert set(state) == {"Xi"}
-    assert np.array_equal(masks[0], masks[1]) and np.array_equal(masks[0], g["dosc_sindy_mask_final"])
+    assert all(np.array_equal(m, g["dosc_sindy_mask_final"]) for m in masks)
+    dev, ref = records["dl1"], records["torch"]
+    assert len(dev) == len(ref) == len(records["quiet"]) == len(g["dosc_sindy_loss_hist"])
+    assert set(dev[0]) == set(ref[0]) == {"loss_sindy_x", "loss_sindy_reg", "test_loss_sindy_x", "test_loss_sindy_z"}
+    assert np.isclose(dev[0]["loss_sindy_x"], ref[0]["loss_sindy_x"], rtol=1e-5)
+    assert np.isclose(dev[0]["test_loss_sindy_x"], ref[0]["test_loss_sindy_x"], rtol=1e-5)
+    assert np.isclose(dev[0]["loss_sindy_reg"], ref[0]["loss_sindy_reg"], rtol=1e-5)
+    # a run that runs out of epochs writes no final checkpoint (the reference saves on final convergence / at the interval)
+    r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV)
+    r.Xi.data = t(g["dosc_sindy_init_Xi"]).to(DEV)
+    S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ident, generator=ident, regressor=r,
+                              **_train_kwargs(num_epochs=2, lr_sindy=0.1, threshold=0.05, st_freq=50, save_dir="short"))
+    assert not os.path.exists("saved_models/short")
 
 
 def test_reversed_regulariser_host_and_device_lbfgs_agree(S, golden, tmp_path, monkeypatch):
@@ -224,12 +246,12 @@ def test_reversed_regulariser_host_and_device_lbfgs_agree(S, golden, tmp_path, m
     Xi0 = t(g[f"{tag}_Xi"])
     dx = O.forward(x, Xi0 * 0.5, torch.ones_like(Xi0), order, bool(sine), bool(exp)).detach()
     out = []
-    for host, kernels in ((True, False), (False, False), (True, True)):     # last: --device_lbfgs (optimiser as device kernels)
+    for host, kernels in ((True, False), (False, False), (True, True)):     # last: the default (optimiser as device kernels)
         r = S.SINDyRegression(d, order, bool(sine), bool(exp), threshold=0.01, device=DEV)
         r.Xi.data = Xi0.to(DEV)
         S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ae, generator=gen, regressor=r,
                                   **_train_kwargs(sym_reg_type="r", w_sym_reg=0.1, num_epochs=3, host_lbfgs=host, threshold=0.01,
-                                                  device_lbfgs=kernels))
+                                                  torch_lbfgs=not kernels))
         out.append((r.Xi.detach().cpu().numpy(), r.mask.cpu().numpy()))
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1])
     # un-converged L-BFGS trajectories (fp32 host vs device arithmetic) after 3 epochs

@@ -23,7 +23,7 @@ def test_parser_defaults_and_flag_names():
     assert (a.sindy_optimizer, a.lbfgs_subsample, a.sym_reg_type, a.w_sym_reg, a.int_t, a.int_dt) == ("adam", 1.0, "i", 0.0, 0.1, 0.01)
     assert (a.repr, a.group_idx, a.ae_arch, a.hidden_dim, a.n_layers, a.seed, a.gpu) == ("(1,so2)", "0", "mlp", 512, 5, 42, 0)
     assert a.eq_constraint is False and a.activation_args == [] and str(a.device) in ("cpu", "cuda:0")
-    assert len(parser_utils._MAIN_ARGS) == 78       # the reference parser's 76 flags (+ --config, --help = its 78 actions) + --lstsq_driver, --device_lbfgs
+    assert len(parser_utils._MAIN_ARGS) == 79       # the reference parser's 76 flags (+ --config, --help = its 78 actions) + --lstsq_driver, --device_lbfgs, --torch_lbfgs
     assert a.lstsq_driver is None                   # = torch.linalg.lstsq's default on the device the data lives on
     s = parser_utils.get_sindy_args(argv=[])
     assert (s.lr, s.reg_type, s.w_reg, s.seq_thres_freq, s.batch_size, s.save_dir) == (1e-3, "l1", 0.1, 100, 64, "sindy-test")
