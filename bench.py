@@ -20,7 +20,10 @@ Prints ONE JSON line (rank 0) following the driver's contract, plus
   roofline_legs : the same for every kernel of the step and for the Euler-flow pair of the infinitesimal regulariser
                   (timed after the K steps on a slice of the resident points; not part of ``value``),
   cpu_baseline  : the CPU oracle ("port" of the reference op sequence) timed on the host cores on a bounded sample of
-                  the same step (rank 0, N = 1 only),
+                  the same step (rank 0, N = 1 only); ``legs``: BASELINE.md section 3's table -- Theta only, closure, one
+                  sequential-threshold pass with full / partial mask, all cores and one thread, median of 20,
+  config3_gram_allreduce : BASELINE config[3]'s sharded work -- 64-seed index-table Gram on this rank's point shard + ONE
+                  fp64 all-reduce of the (64, 12, 12) stack: kernel us, collective us, ranks observed (every N),
   single_problem: the bare 50x2500x2 shape, kernel time and closure wall time.
   seed_sweeps: wall time of the 64-seed L-BFGS and sequential-threshold sweeps at BASELINE config[3]'s size (informational).
 """
@@ -56,6 +59,7 @@ def parse(argv=None):
     ap.add_argument("--chunks", type=int, default=0, help="problem chunks per step; chunk c's all-reduce overlaps chunk c+1's kernels (default: 1 on one GPU, 2 when the [loss|grad] buffer is all-reduced)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
+    ap.add_argument("--config3", action="store_true", help="run the config[3] Gram + all-reduce leg even in a --profile run")
     ap.add_argument("--no_sweeps", action="store_true", help="skip the informational seed-sweep timings (N = 1 only)")
     ap.add_argument("--shard", choices=["points", "seeds"], default="points",
                     help="N > 1: 'points' = every rank holds a shard of each problem's trajectories and the packed "
@@ -238,6 +242,152 @@ def seed_sweeps(eng, dev):
     return out
 
 
+def _median_ms(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline_legs(x1, dx1, Xi1, order, eng=None, dev=None, reps=20):
+    """BASELINE.md section 3's protocol on ONE 50x2500x2 problem: the reference's op sequence (oracle) for (i) Theta only,
+    (ii) closure body forward + backward, (iii) one sequential-threshold pass with the full mask and with a partial one
+    (the dense block_diag system of sindy.py:270-273) -- each with all host cores of this job and with ONE thread, 3
+    warm-ups, median of ``reps`` (>= 20) repetitions; beside every leg the product's time for the same operation on the
+    GPU (wall time with a synchronisation per call, same protocol)."""
+    import torch
+    from oracle import sindy_oracle as O
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    all_cores = max(1, min(16, avail))                   # a 1-GPU job owns a 16-core share of the box
+    n_pts, d = x1.shape
+    p = O.term_count(d, order)
+    g = torch.Generator().manual_seed(5)
+    partial = (torch.rand(d, p, generator=g) > 0.4).float()
+    partial[:, 1:3] = 1.0
+
+    def cpu_ops():
+        reg = O.OracleRegressor(d, order, Xi0=Xi1.clone())
+
+        def closure():
+            reg.Xi.grad = None
+            torch.nn.functional.mse_loss(reg(x1), dx1).backward()
+
+        def stlsq(mask):
+            def run():
+                r2 = O.OracleRegressor(d, order, Xi0=Xi1.clone())
+                r2.mask = mask.clone()
+                O.stlsq_one_step(r2, x1, dx1, 0.05, 0.05, lstsq=torch.linalg.lstsq)      # the reference's own solver call
+            return run
+        return {"theta": lambda: O.theta(x1, order), "closure": closure, "stlsq_full_mask": stlsq(torch.ones(d, p)),
+                "stlsq_partial_mask": stlsq(partial)}
+
+    legs = {k: {"points": n_pts} for k in ("theta", "closure", "stlsq_full_mask", "stlsq_partial_mask")}
+    for label, nt in (("all_cores", all_cores), ("one_thread", 1)):
+        torch.set_num_threads(nt)
+        for name, fn in cpu_ops().items():
+            ms = _median_ms(fn, reps=reps)
+            legs[name][f"cpu_ms_{label}"] = ms
+            legs[name][f"cpu_points_per_s_{label}"] = n_pts / (ms * 1e-3)
+    torch.set_num_threads(all_cores)
+    if eng is not None:
+        from symode_amd.sindy import SINDyRegression, solve_SINDy_one_step
+        xg, dxg, Xig = x1.to(dev), dx1.to(dev), Xi1.to(dev)
+        out = (torch.empty(1, device=dev), torch.empty(d, p, device=dev))
+
+        def sync(fn):
+            def run():
+                fn()
+                torch.cuda.synchronize()
+            return run
+
+        def gpu_stlsq(mask):
+            def run():
+                r = gpu_stlsq.reg
+                r.mask.copy_(mask.to(dev))
+                solve_SINDy_one_step(r, xg, dxg, 0.05, 0.05)
+            return run
+        gpu_stlsq.reg = SINDyRegression(d, order, False, False, threshold=0.05, device=dev)
+        for name, fn in (("theta", lambda: eng.theta(xg, order)), ("closure", lambda: eng.loss_grad(xg, dxg, Xig, None, order, out=out)),
+                         ("stlsq_full_mask", gpu_stlsq(torch.ones(d, p))), ("stlsq_partial_mask", gpu_stlsq(partial))):
+            ms = _median_ms(sync(fn), reps=reps)
+            legs[name]["gpu_ms"] = ms
+            legs[name]["gpu_points_per_s"] = n_pts / (ms * 1e-3)
+    return {"protocol": f"one problem of {n_pts} points x {d}, order {order} (p = {p}); 3 warm-ups, median of {reps}; CPU = the "
+                        "oracle's restatement of the reference's op sequence (torch.linalg.lstsq on the ridge-augmented / "
+                        "block-diagonal system), GPU = the product's call for the same operation incl. launch and synchronisation",
+            "os_cpu_count": os.cpu_count(), "cores_available": avail, "torch_num_threads_all_cores": all_cores, "legs": legs}
+
+
+def config3_leg(eng, dev, rank, world, group, gloo, reps=20):
+    """BASELINE config[3]: selkov n_ics=10 x 10 000 steps, 64 seeds x 50 % subsample, order 3 -- every seed's subsample is
+    drawn once (seeded by the seed alone), rank r gathers rows [r m / W, (r+1) m / W) of every draw with ONE index-table Gram
+    launch (symode_aug_gram_gather, fp64), and ONE all-reduce sums the (64, 12, 12) fp64 stack over the ranks (RCCL over
+    xGMI; gloo in a rehearsal); the 64 threshold loops then run on the host from the summed matrices (identical on every rank).
+    Reports the kernel time (HIP events on the launch stream), the collective time, and the whole sweep's wall time; rank 0
+    also forms the full-subsample Gram alone and checks the all-reduced stack against it."""
+    import torch
+    import torch.distributed as dist
+    from symode_amd import data
+    from symode_amd.sweep import SeedSweepSTLSQ, seeded_subsamples
+    S, order = 64, 3
+    xs, dxs = data.make_dataset("selkov", 10, 10000, dt=0.002, noise=0.2, seed=3, device=dev)
+    x_all, dx_all = xs[0].reshape(-1, 2).contiguous(), dxs[0].reshape(-1, 2).contiguous()
+    n_all = x_all.shape[0]
+    m = n_all // 2
+    rows = seeded_subsamples(n_all, m, list(range(S)), dev)                  # (S, m): the same table on every rank
+    lo, hi = rank * m // world, (rank + 1) * m // world
+    idx = rows[:, lo:hi].to(torch.int32).contiguous()
+    for _ in range(3):
+        G = eng.aug_gram_gather(x_all, dx_all, idx, order, 0)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record()
+        G = eng.aug_gram_gather(x_all, dx_all, idx, order, 0)
+        e1.record()
+    torch.cuda.synchronize()
+    kern = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev)
+    out = {"shape": f"selkov 10 x 10000 x 2, {S} seeds x {m} points (50 % subsample), order 3; this rank gathers {hi - lo} rows per seed",
+           "gram_kernel_us": kern[len(kern) // 2], "gram_kernel_us_min": kern[0], "gram_bytes_per_launch": S * (hi - lo) * (16 + 4),
+           "allreduce_us": None, "allreduce_bytes": S * 12 * 12 * 8, "ranks": world}
+    out["gram_GBs"] = out["gram_bytes_per_launch"] / (out["gram_kernel_us"] * 1e-6) / 1e9
+    if group is not None:
+        coll = []
+        for _ in range(reps + 3):
+            Gc = G.clone()
+            torch.cuda.synchronize()
+            dist.barrier(group=group)
+            t0 = time.perf_counter()
+            dist.all_reduce(Gc, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize()
+            coll.append((time.perf_counter() - t0) * 1e6)
+        coll = sorted(coll[3:])
+        out["allreduce_us"] = coll[len(coll) // 2]
+        out["allreduce_us_min"] = coll[0]
+        out["allreduce_backend"] = "gloo (rehearsal)" if gloo else "nccl (RCCL)"
+        counted = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(counted, group=group)
+        out["ranks_observed"] = int(round(counted.item()))
+    # the whole sweep as main_sweep --method stlsq runs it: Gram launch + collective + 64 host threshold loops
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sw = SeedSweepSTLSQ(x_all, dx_all, order, n_seeds=S, group=group, engine=eng, idx=idx)
+    Xi, mask, passes = sw.solve(0.0, 0.075, max_iter=10)
+    out["sweep_wall_ms"] = (time.perf_counter() - t0) * 1e3
+    out["stlsq_passes"] = int(passes.sum())
+    out["masks_sha"] = __import__("hashlib").sha256(mask.numpy().astype("uint8").tobytes()).hexdigest()[:16]
+    if rank == 0:
+        full = eng.aug_gram_gather(x_all, dx_all, rows.to(torch.int32).contiguous(), order, 0).cpu().numpy()
+        got = sw.grams()
+        out["allreduced_vs_single_rank_max_rel_err"] = float(abs(got - full).max() / abs(full).max())
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -413,6 +563,14 @@ def main():
                           "20 back-to-back launches replayed from a HIP graph; closure_us: host wall time of one closure of the "
                           "L-BFGS trainer (coefficients in, [loss | grad] out through pinned memory, one launch, one sync)"}
 
+    # ---- BASELINE config[3]: 64-seed index-table Gram on point shards + ONE fp64 all-reduce of the (64, 12, 12) stack ----
+    c3 = None
+    if (not a.profile and not a.no_sweeps) or a.config3:
+        try:
+            c3 = config3_leg(eng, dev, rank, world, dist.group.WORLD if use_dist else None, a.rehearse_gloo)
+        except Exception as e:                               # an informational leg never fails the bench line
+            c3 = {"error": f"{type(e).__name__}: {e}"}
+
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -442,6 +600,8 @@ def main():
     }
     if single:
         res["single_problem"] = single
+    if c3 is not None:
+        res["config3_gram_allreduce"] = c3
     if world == 1 and not a.profile and not a.no_sweeps:
         res["seed_sweeps"] = seed_sweeps(eng, dev)
     if world == 1 and not a.no_cpu_baseline and not a.profile:
@@ -456,6 +616,8 @@ def main():
             single["cpu_points_per_s"] = cpu1["value"]
             single["cpu_cores"] = cpu1["cores"]
             single["speedup_vs_cpu"] = single["points_per_s"] / cpu1["value"]
+        # Theta-only / closure / STLSQ full + partial mask, all cores and one thread, median of >= 20
+        res["cpu_baseline"].update(cpu_baseline_legs(x[0].cpu(), dx[0].cpu(), torch.randn(d, clos.p) * 0.3, order, eng, dev))
     print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

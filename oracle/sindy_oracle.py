@@ -260,12 +260,15 @@ def lstsq_cpu(A: torch.Tensor, B: torch.Tensor) -> _LstsqResult:
     return _LstsqResult(torch.from_numpy(np.ascontiguousarray(sol)).to(A.dtype), torch.empty(0, dtype=A.dtype), rank)
 
 
-def stlsq_one_step(reg: OracleRegressor, x, y, w_sindy_reg, st_threshold):
+def stlsq_one_step(reg: OracleRegressor, x, y, w_sindy_reg, st_threshold, lstsq=None):
     """One ridge-augmented least-squares solve + hard threshold.   ref: sindy.py:250-315
 
     Returns (residual, converged, solution).  ``residual`` follows the reference literally
     (``lm.residuals.mean() / N``), which is NaN on CPU where lstsq returns no residuals.
+    ``lstsq``: the solver called at sindy.py:288 -- default ``lstsq_cpu`` (see there); bench.py's timed CPU baseline
+    passes ``torch.linalg.lstsq``, the reference's own call.
     """
+    lstsq = lstsq or lstsq_cpu
     theta_x = reg.theta(x)                                                               # :261
     p = theta_x.shape[1]
     A = torch.cat([theta_x, w_sindy_reg * torch.eye(p)], dim=0)                          # :262-263
@@ -285,7 +288,7 @@ def stlsq_one_step(reg: OracleRegressor, x, y, w_sindy_reg, st_threshold):
             A = A @ Q[mask.flatten()]                                                    # :282
             effective = torch.any(A != 0.0, dim=0)                                       # :284
             A = A[:, effective]
-    lm = lstsq_cpu(A, B)                                                                 # :288
+    lm = lstsq(A, B)                                                                     # :288
     sol = lm.solution
     prev_mask = reg.mask.clone()
     with torch.no_grad():

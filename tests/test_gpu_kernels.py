@@ -536,7 +536,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse_gloo", "--problems", "64", "--steps", "3",
-                          "--warmup", "1", "--no_cpu_baseline", "--profile", "--master_port", "29533"], env=env, stdout=subprocess.PIPE,
+                          "--warmup", "1", "--no_cpu_baseline", "--profile", "--config3", "--master_port", "29533"], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -545,6 +545,12 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert rec["n_gpus"] == 2 and rec["config"]["ranks_observed"] == 2 and rec["warmup"] == 1 and rec["steps"] == 3
     assert rec["metric"].endswith("sym-reg") and len(rec["roofline_legs"]) == 1 and rec["value"] > 0      # ONE fused closure kernel per step
     assert "x read once" in rec["roofline"]["kernel"] and rec["roofline"]["bytes_per_point"] == 40
+    # BASELINE config[3]'s sharded work: 64-seed index-table Gram on each rank's half of every subsample + ONE fp64
+    # all-reduce of the (64, 12, 12) stack, checked against the single-rank Gram of the whole subsample
+    c3 = rec["config3_gram_allreduce"]
+    assert "error" not in c3, c3
+    assert c3["ranks"] == 2 and c3["ranks_observed"] == 2 and c3["allreduce_bytes"] == 64 * 144 * 8
+    assert c3["gram_kernel_us"] > 0 and c3["allreduce_us"] > 0 and c3["allreduced_vs_single_rank_max_rel_err"] < 1e-12
 
 
 @pytest.mark.parametrize("d,order,fl,K,n", only_compiled([(2, 2, 2, 10, 20000), (2, 3, 0, 3, 4097), (3, 2, 0, 5, 3001), (1, 4, 1, 16, 1000),

@@ -235,6 +235,24 @@ def test_device_lbfgs_path_writes_logs_and_interval_checkpoints(S, golden, tmp_p
     assert not os.path.exists("saved_models/short")
 
 
+@pytest.mark.parametrize("torch_opt", [False, True], ids=["device_trainer", "torch_lbfgs"])
+def test_nan_gradient_ends_the_fit_with_the_reference_message(S, golden, tmp_path, monkeypatch, capsys, torch_opt):
+    """A NaN in the data makes loss and gradient NaN at the finite start: torch.optim.LBFGS does not stop on a NaN gradient
+    (`<=` test), the parameters go to NaN and train.py:697-699 ends the run -- on the device trainer as on torch's optimiser."""
+    monkeypatch.chdir(tmp_path)
+    g = golden("f4_lbfgs")
+    x, dx = t(g["dosc_sindy_x"]), t(g["dosc_sindy_dx"]).clone()
+    dx[17, 1] = float("nan")
+    r = S.SINDyRegression(2, 3, False, False, threshold=0.05, device=DEV)
+    r.Xi.data = t(g["dosc_sindy_init_Xi"]).to(DEV)
+    ident = torch.nn.Identity()
+    S.train.train_SIGED_lbfgs(train_loader=[(x, dx)], autoencoder=ident, generator=ident, regressor=r,
+                              **_train_kwargs(num_epochs=5, lr_sindy=0.1, torch_lbfgs=torch_opt, save_dir="nan"))
+    out = capsys.readouterr().out
+    assert "NaN encountered at iteration 0; exit training." in out and "Final convergence" not in out
+    assert torch.isnan(r.Xi).any() and not os.path.exists("saved_models/nan")
+
+
 def test_reversed_regulariser_host_and_device_lbfgs_agree(S, golden, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     g = golden("f6_symreg")

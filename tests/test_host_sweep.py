@@ -108,3 +108,39 @@ def test_lbfgs_sweep_with_constrained_constant_matches_sequential_runs():
         assert np.allclose((out["Xi"][s] * out["mask"][s]).numpy(), (reg.get_Xi() * reg.mask).detach().numpy(), rtol=2e-3, atol=2e-4), s
         assert torch.equal(out["params"][s, Q.shape[1]:], inits[s, Q.shape[1]:])      # the unread constant never moves
     assert np.array_equal(out["mask"][0].numpy() > 0, truth)
+
+
+def test_nan_gradient_at_finite_parameters_ends_the_run_with_the_nan_flag():
+    """torch.optim.LBFGS.step tests ``flat_grad.abs().max() <= tolerance_grad`` at its top: a NaN gradient does not stop
+    the step, the parameters go to NaN and the trainer's NaN guard (train.py:697) ends the run.  A problem whose closure
+    returns NaN gradients at finite parameters must therefore come out with nan = True, finished = False -- not frozen at
+    its finite start and reported converged."""
+    class NaNClosure:                        # the interface SeedSweepLBFGS uses of BatchedClosure, two problems
+        S, d, p, Q, distributed = 2, 1, 3, None, False
+
+        def evaluate(self, beta, const=None, mask=None):
+            g = 2.0 * beta.reshape(self.S, -1)
+            loss = (beta.reshape(self.S, -1) ** 2).sum(1)
+            g = g.clone()
+            g[1] = float("nan")              # problem 1: NaN gradient (and a finite loss) at finite parameters
+            return loss, g.reshape(self.S, self.d, self.p), None
+
+        def xi_from(self, beta, const=None):
+            return beta
+
+    P0 = torch.tensor([[1.0, -2.0, 0.5], [0.3, 0.2, -0.1]])
+    out = SeedSweepLBFGS(NaNClosure(), 0.1, 0.05, 50).fit(P0, 10)
+    assert out["nan"].tolist() == [False, True] and out["finished"].tolist()[1] is False
+    assert int(out["epochs"][1]) == 1                     # the guard fires after the first epoch
+    assert torch.isnan(out["params"][1]).all() and torch.isfinite(out["params"][0]).all()
+    # torch's own optimiser on the same closure: NaN parameters after one step as well
+    w = P0[1].clone().requires_grad_(True)
+    opt = torch.optim.LBFGS([w], lr=0.1)
+
+    def cl():
+        opt.zero_grad()
+        loss = (w ** 2).sum()
+        w.grad = torch.full_like(w, float("nan"))
+        return loss
+    opt.step(cl)
+    assert torch.isnan(w).all()
