@@ -18,6 +18,45 @@ import torch.distributed as dist
 from .engine import get_engine, library_flags
 
 
+def allreduce_sums(sums, params, group):
+    """Point-sharded scalar sums and their parameter gradients through ONE collective.
+
+    ``sums``: scalar tensors, each a sum over THIS rank's points (with or without an autograd graph); ``params``: the
+    leaf tensors they are differentiated by.  Every sum is differentiated locally, the values and gradients of all of
+    them travel in one packed fp64 buffer (n * (1 + |params|) numbers -- a few hundred bytes) through one all-reduce,
+    and what comes back is, per sum, a scalar tensor whose VALUE is the global sum and whose first derivative with
+    respect to ``params`` is the global gradient (value + g . (p - p.detach())).  Whatever the caller builds from them
+    -- a mean, a ratio of two batch means (the relative regularisers, model_utils.py:62, 118-121: numerator and
+    denominator must be summed over the ranks SEPARATELY before the division) -- autograd differentiates on that
+    handful of scalars: the quotient rule is applied after the collective, on global numbers, on every rank alike."""
+    params = list(params)
+    sizes = [p.numel() for p in params]
+    P = sum(sizes)
+    dev = sums[0].device
+    buf = torch.zeros(len(sums), 1 + P, dtype=torch.float64, device=dev)
+    for i, s in enumerate(sums):
+        buf[i, 0] = s.detach()
+        if s.requires_grad:
+            gs = torch.autograd.grad(s, params, retain_graph=True, allow_unused=True)
+            o = 1
+            for g, n in zip(gs, sizes):
+                if g is not None:
+                    buf[i, o:o + n] = g.reshape(-1)
+                o += n
+    if group is not None:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    out = []
+    for i in range(len(sums)):
+        v = buf[i, 0].to(sums[i].dtype)
+        o = 1
+        for p, n in zip(params, sizes):
+            g = buf[i, o:o + n].to(p.dtype).view_as(p)
+            v = v + (g * (p - p.detach())).sum()
+            o += n
+        out.append(v)
+    return out
+
+
 class BatchedClosure:
     def __init__(self, x, dx, poly_order, include_sine=False, include_exp=False, Q=None, use_kron_product=True,
                  allow_constant=True, group=None, world_size=None, n_chunks=1, engine=None, reversed_sym=None, fuse_sym=True):

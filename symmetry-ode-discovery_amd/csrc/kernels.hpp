@@ -916,60 +916,66 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
 
     // the first generator is read ONCE (uniform -> scalar registers): with one generator -- every fixed group of the
-    // reference, a single learned channel -- no scalar load is left inside the point loop
+    // reference, a single learned channel -- no scalar load is left inside the point loop and the loop over the further
+    // generators is one skipped uniform branch
     float L0[D][D];
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
         for (int b = 0; b < D; ++b) L0[a][b] = n_gen > 0 ? Lg[a * D + b] : 0.0f;
+    auto one_gen = [&](const float (&zp)[D], const float (&L)[D][D]) {
+        float v[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            float t = 0.0f;
+#pragma unroll
+            for (int b = 0; b < D; ++b) t = fmaf(L[a][b], zp[b], t);
+            v[a] = t;
+        }
+        float th[P], dth[P], h[D], jv[D], u[D], ltu[D];
+        Lib::eval_jvp(zp, v, th, dth);
+        apply_xi<Lib>(w, th, h);
+        apply_xi<Lib>(w, dth, jv);
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            float t = jv[a];
+#pragma unroll
+            for (int b = 0; b < D; ++b) t = fmaf(-L[a][b], h[b], t);
+            u[a] = t;
+            acc[0] = fmaf(t, t, acc[0]);
+        }
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            float t = 0.0f;
+#pragma unroll
+            for (int a = 0; a < D; ++a) t = fmaf(L[a][b], u[a], t);
+            ltu[b] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                acc[1 + j * P + k] = fmaf(u[j], dth[k], fmaf(-ltu[j], th[k], acc[1 + j * P + k]));
+    };
     auto one = [&](const float (&zp)[D]) {
-        for (int g = 0; g < n_gen; ++g) {
+        if (n_gen > 0) one_gen(zp, L0);
+        for (int g = 1; g < n_gen; ++g) {
             float L[D][D];
 #pragma unroll
             for (int a = 0; a < D; ++a)
 #pragma unroll
-                for (int b = 0; b < D; ++b) L[a][b] = (g == 0) ? L0[a][b] : Lg[(g * D + a) * D + b];
-            float v[D];
-#pragma unroll
-            for (int a = 0; a < D; ++a) {
-                float t = 0.0f;
-#pragma unroll
-                for (int b = 0; b < D; ++b) t = fmaf(L[a][b], zp[b], t);
-                v[a] = t;
-            }
-            float th[P], dth[P], h[D], jv[D], u[D], ltu[D];
-            Lib::eval_jvp(zp, v, th, dth);
-            apply_xi<Lib>(w, th, h);
-            apply_xi<Lib>(w, dth, jv);
-#pragma unroll
-            for (int a = 0; a < D; ++a) {
-                float t = jv[a];
-#pragma unroll
-                for (int b = 0; b < D; ++b) t = fmaf(-L[a][b], h[b], t);
-                u[a] = t;
-                acc[0] = fmaf(t, t, acc[0]);
-            }
-#pragma unroll
-            for (int b = 0; b < D; ++b) {
-                float t = 0.0f;
-#pragma unroll
-                for (int a = 0; a < D; ++a) t = fmaf(L[a][b], u[a], t);
-                ltu[b] = t;
-            }
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-#pragma unroll
-                for (int k = 0; k < P; ++k)
-                    acc[1 + j * P + k] = fmaf(u[j], dth[k], fmaf(-ltu[j], th[k], acc[1 + j * P + k]));
+                for (int b = 0; b < D; ++b) L[a][b] = Lg[(g * D + a) * D + b];
+            one_gen(zp, L);
         }
     };
-    for_each_point<D, BLOCK>(
-        N, vec,
-        [&](long c) {
-            float zp[PPT][D];
-            load_chunk<D>(z, c, zp);
+    // 8 bytes per point against ~115 vector instructions: the stream is thin, but a wave that waits out every miss
+    // idles its SIMD -- four chunks per lane in flight (points.hpp, for_each_chunk_ring)
+    const float* const arrs[1] = {z};
+    for_each_chunk_ring<D, BLOCK, 4, 1>(
+        N, vec, arrs,
+        [&](long, const float (&zp)[1][PPT][D]) {
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) one(zp[i]);
+            for (int i = 0; i < PPT; ++i) one(zp[0][i]);
         },
         [&](long n) {
             float zp[D];

@@ -243,4 +243,73 @@ __device__ __forceinline__ void for_each_chunk2(long N, bool vec, Load load, Com
     }
 }
 
+// Register-ring pipeline over NA operand arrays of one (N, D) problem: every lane keeps R chunks of every operand in
+// flight -- the slot a chunk has just been consumed from is refilled at once with the chunk R rounds ahead (16-byte
+// non-temporal loads; indices past the end are clamped to the last chunk, so the tail over-reads in bounds and the
+// vmcnt arithmetic stays uniform).  compute(c, p) receives the unpacked points p[a][i][:] of chunk c of operand a.
+// Why: a reduction launch is a few long-lived workgroups (its partial rows must stay few), so unlike the index-space
+// maps nothing but the wave's own run-ahead hides the HBM latency; with the two-chunk form a wave of the 8-byte-per-point
+// regulariser issued one 16-byte load per ~230 vector instructions and waited out every miss (0.55 of the issue slots).
+// D = 3 keeps the two-chunk form: its 12-byte points come through the wave's coalesced-tile exchange (load_chunk).
+template <int D, int BLOCK, int R, int NA, typename Compute, typename PointBody>
+__device__ __forceinline__ void for_each_chunk_ring(long N, bool vec, const float* const (&arr)[NA], Compute compute,
+                                                    PointBody point_body) {
+    constexpr int PPT = Chunk<D>::PPT, NV = Chunk<D>::NV;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
+    const long nthreads = (long)gridDim.x * BLOCK;
+    if (!vec) {
+        for (long n = tid; n < N; n += nthreads) point_body(n);
+        return;
+    }
+    const long nchunks = N / PPT;
+    if constexpr (D == 3) {
+        long c = tid;
+        for (; c + nthreads < nchunks; c += 2 * nthreads) {
+            float a[NA][PPT][D], b[NA][PPT][D];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c, a[q]);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c + nthreads, b[q]);
+            compute(c, a);
+            compute(c + nthreads, b);
+        }
+        if (c < nchunks) {
+            float a[NA][PPT][D];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c, a[q]);
+            compute(c, a);
+        }
+    } else if (nchunks > 0) {
+        const long lastc = nchunks - 1;
+        float4 ring[R][NA][NV];
+        auto ld = [&](long cc, float4 (&slot)[NA][NV]) {
+            const long q = cc < lastc ? cc : lastc;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) load_chunk_raw<D, true>(arr[a], q, slot[a]);
+        };
+        auto use = [&](long cc, const float4 (&slot)[NA][NV]) {
+            float pts[NA][PPT][D];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) unpack_chunk<D>(slot[a], pts[a]);
+            compute(cc, pts);
+        };
+        long c = tid;
+#pragma unroll
+        for (int k = 0; k < R; ++k) ld(c + k * nthreads, ring[k]);
+        for (; c + (R - 1) * nthreads < nchunks; c += R * nthreads) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                use(c + k * nthreads, ring[k]);
+                ld(c + (R + k) * nthreads, ring[k]);
+                __builtin_amdgcn_sched_barrier(0);       // keep the refill here: the scheduler would sink all R to the loop end
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (c + k * nthreads < nchunks) use(c + k * nthreads, ring[k]);
+    }
+    const long n = nchunks * PPT + tid;
+    if (n < N) point_body(n);
+}
+
 }  // namespace symode

@@ -264,11 +264,46 @@ def _const_half(kind, x_const, autoencoder, generator, blocks, zm, n_comps, x_fx
     return hit[2], hit[3]
 
 
+def _sharded_params(f, params):
+    if params is not None:
+        return list(params)
+    reg = getattr(f, 'regressor', None)
+    if reg is None:
+        raise ValueError('group=...: pass params= (the tensors f depends on) unless f is the Euler flow of a regressor.')
+    return list(reg.parameters())
+
+
+def _finish_sharded(nums, dens, count, relative, params, group, also):
+    """``nums`` / ``dens``: per-generator sums of squares over THIS rank's points.  The relative loss is a ratio of two
+    batch means (model_utils.py:62, 118-121), so numerators, denominators and their gradients cross the ranks
+    separately -- in ONE packed buffer (batched.allreduce_sums) together with whatever else the closure needs summed
+    (``also``: e.g. the residual's sum of squares) -- and the division happens after the collective."""
+    from .batched import allreduce_sums
+    cnt = torch.tensor(float(count), device=nums[0].device)
+    n = len(nums)
+    red = allreduce_sums(list(nums) + (list(dens) if relative else []) + [cnt] + list(also or []), params, group)
+    loss = 0.0
+    for k in range(n):
+        loss = loss + (red[k] / red[n + k] if relative else red[k] / red[n].detach())
+    extra = red[(2 * n if relative else n) + 1:]
+    return loss if also is None else (loss, extra)
+
+
 # --------------------------------------------------------------------------------------------
 # S2: infinitesimal                                                   ref: model_utils.py:8-67
 # --------------------------------------------------------------------------------------------
 def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global', z_mean=None, relative=True,
-              require_grad=False, numpy=False, x_const=None):
+              require_grad=False, numpy=False, x_const=None, group=None, also=None, params=None):
+    """``group`` (a torch.distributed process group): ``x_fx`` is this rank's POINT SHARD of the batch.
+    Returns the loss of the whole batch -- per generator, numerator and denominator of the relative loss and their
+    parameter gradients are summed locally, all-reduced in one packed buffer, and the ratio is formed after the
+    collective; the returned scalar carries the global first derivative with respect to ``params`` (default: the
+    parameters of the regressor behind ``f``), identical on every rank.  ``also``: further local sums to ride in the same
+    buffer; then ``(loss, [global sums])`` is returned."""
+    sharded = group is not None or also is not None
+    if sharded and (numpy or not require_grad or normalize == 'in_batch'):
+        raise ValueError('group=... needs require_grad=True, torch inputs and a batch-independent normalisation.')
+    nums, dens = [], []
     if numpy:
         x_fx = torch.from_numpy(x_fx).float().to(autoencoder.device)
         if z_mean is not None:
@@ -296,8 +331,14 @@ def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global
                     v_fx = _module_jvp(autoencoder.decoder, z1.reshape(-1, nc, z1.shape[-1]),
                                        (z1 @ L.T).reshape(-1, nc, z1.shape[-1]), require_grad).reshape(fx.shape[0], -1)
                     input_variation = f.tangent(x, v_x)[1] if isinstance(f, _EulerFlow) else jvp_fn(f, x, v_x)[1]
+                    if sharded:
+                        nums.append(torch.sum((input_variation - v_fx) ** 2))
+                        dens.append(torch.sum(input_variation ** 2))
+                        continue
                     err = torch.mean((input_variation - v_fx) ** 2)
                     loss += err / torch.mean(input_variation ** 2) if relative else err
+                if sharded:
+                    return _finish_sharded(nums, dens, fx.numel(), relative, _sharded_params(f, params), group, also)
             return loss
     with torch.set_grad_enabled(require_grad):
         loss = 0.0
@@ -319,10 +360,15 @@ def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global
                     input_variation = jvp_fn(f, x, v_x)[1]                       # arbitrary f: autograd
             else:
                 input_variation = torch.einsum('bjk,bk->bj', dfdx, v_x)
-            if not relative:
+            if sharded:
+                nums.append(torch.sum((input_variation - v_fx) ** 2))
+                dens.append(torch.sum(input_variation ** 2))
+            elif not relative:
                 loss += torch.mean((input_variation - v_fx) ** 2)
             else:
                 loss += torch.mean((input_variation - v_fx) ** 2) / torch.mean(input_variation ** 2)
+        if sharded:
+            return _finish_sharded(nums, dens, x.numel(), relative, _sharded_params(f, params), group, also)
     if numpy:
         loss = loss.cpu().numpy()
     return loss
@@ -332,7 +378,12 @@ def symmreg_i(x_fx, autoencoder, generator, f=None, dfdx=None, normalize='global
 # S3: finite                                                         ref: model_utils.py:69-124
 # --------------------------------------------------------------------------------------------
 def symmreg_f(x_fx, autoencoder, generator, f, normalize='global', z_mean=None, relative=True, require_grad=False,
-              numpy=False, x_const=None):
+              numpy=False, x_const=None, group=None, also=None, params=None):
+    """``group`` / ``also`` / ``params``: point-sharded evaluation, as in symmreg_i."""
+    sharded = group is not None or also is not None
+    if sharded and (numpy or not require_grad or normalize == 'in_batch'):
+        raise ValueError('group=... needs require_grad=True, torch inputs and a batch-independent normalisation.')
+    nums, dens = [], []
     autoencoder.eval()
     generator.eval()
     if numpy:
@@ -354,8 +405,14 @@ def symmreg_f(x_fx, autoencoder, generator, f, normalize='global', z_mean=None, 
                 for G, g_x in zip(blocks, g_xs):
                     g_fx = _by_rows(autoencoder.decode, z1 @ G.T + zm, nc)
                     f_g_x = f(g_x)
+                    if sharded:
+                        nums.append(torch.sum((f_g_x - g_fx) ** 2))
+                        dens.append(torch.sum((f_g_x - fx) ** 2))
+                        continue
                     err = torch.mean((f_g_x - g_fx) ** 2)
                     loss += err / torch.mean((f_g_x - fx) ** 2) if relative else err
+                if sharded:
+                    return _finish_sharded(nums, dens, fx.numel(), relative, _sharded_params(f, params), group, also)
             return loss
     with torch.set_grad_enabled(require_grad):
         loss = 0.0
@@ -376,10 +433,15 @@ def symmreg_f(x_fx, autoencoder, generator, f, normalize='global', z_mean=None, 
             f_g_x = f(g_x)
             if numpy:
                 f_g_x = torch.from_numpy(f_g_x).float().to(generator.Li[0].device)
-            if not relative:
+            if sharded:
+                nums.append(torch.sum((f_g_x - g_fx) ** 2))
+                dens.append(torch.sum((f_g_x - fx) ** 2))
+            elif not relative:
                 loss += torch.mean((f_g_x - g_fx) ** 2)
             else:
                 loss += torch.mean((f_g_x - g_fx) ** 2) / torch.mean((f_g_x - fx) ** 2)
+        if sharded:
+            return _finish_sharded(nums, dens, fx.numel(), relative, _sharded_params(f, params), group, also)
     if numpy:
         loss = loss.cpu().numpy()
     return loss

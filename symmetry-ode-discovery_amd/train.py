@@ -21,6 +21,7 @@ import os
 import numpy as np
 import torch
 
+from .batched import allreduce_sums
 from .model_utils import (_EulerFlow, make_fsymmreg_pttrain, make_rsymmreg_pttrain, make_symmreg_pttrain, odeint,
                           symmreg_linear)
 from .sindy import solve_SINDy, solve_SINDy_one_step
@@ -882,6 +883,9 @@ def train_SIGED_lbfgs(
     generator.eval()
     losses = {}
     print_eq = kwargs.get('print_eq', False)
+    group = kwargs.get('group')                # point shards: x, dx of train_loader are this rank's slice of the batch
+    if group is not None and use_latent:
+        raise ValueError('group=... (point shards) is implemented for the non-latent fit.')
 
     def reg_term(reg, loss):
         if sindy_reg_type == 'l1':                                                     # raw (unmasked) params, :680-683
@@ -906,8 +910,25 @@ def train_SIGED_lbfgs(
             loss = w_sindy_z * loss_sindy_z + w_sindy_x * loss_sindy_x
         else:
             loss_sindy_x = regressor.mse_loss(x, dx)                                   # fused HIP kernel
-            losses['loss_sindy_x'] = loss_sindy_x.detach()
-            if w_sym_reg > 0.0:
+            loss_sym_reg = 0.0
+            if group is not None:
+                # x, dx are this rank's point shard: the residual's sum of squares, the point count and -- for the relative
+                # regularisers, per generator -- numerator and denominator cross the ranks with their gradients in ONE
+                # packed all-reduce; means and ratios are formed after it (model_utils.py:62, 118-121)
+                n_loc = float(x.numel())
+                also = [loss_sindy_x * n_loc, torch.tensor(n_loc, device=x.device)]
+                if w_sym_reg > 0.0 and sym_reg_type in ['i', 'f']:
+                    forward_step = _EulerFlow(regressor, int_t, int_dt)
+                    x_fx = torch.stack([x, forward_step(x)], dim=1)
+                    loss_sym_reg, red = symm_loss(x_fx, f=forward_step, x_const=x, group=group, also=also)
+                else:
+                    if w_sym_reg > 0.0:                                                # 'r': a plain batch mean per group element
+                        also.append(symm_loss(x, h=regressor) * n_loc)
+                    red = allreduce_sums(also, list(regressor.parameters()), group)
+                    if w_sym_reg > 0.0:
+                        loss_sym_reg = red[2] / red[1]
+                loss_sindy_x = red[0] / red[1]
+            elif w_sym_reg > 0.0:
                 if sym_reg_type in ['i', 'f']:
                     forward_step = _EulerFlow(regressor, int_t, int_dt)
                     fx_pred = forward_step(x)
@@ -915,9 +936,9 @@ def train_SIGED_lbfgs(
                     loss_sym_reg = symm_loss(x_fx, f=forward_step, x_const=x)
                 elif sym_reg_type == 'r':
                     loss_sym_reg = symm_loss(x, h=regressor)
+            losses['loss_sindy_x'] = loss_sindy_x.detach()
+            if w_sym_reg > 0.0:
                 losses['loss_sym_reg'] = loss_sym_reg.detach()
-            else:
-                loss_sym_reg = 0.0
             loss = w_sindy_x * loss_sindy_x + w_sym_reg * loss_sym_reg
         loss = reg_term(regressor, loss)
         loss.backward()
@@ -940,7 +961,7 @@ def train_SIGED_lbfgs(
                  and os.environ.get('SYMODE_TORCH_OPTIM', '0') != '1' and w_sindy_x > 0 and sindy_reg_type in ('l1', 'none')
                  and hasattr(getattr(regressor.engine, 'lib', None), 'symode_trainer_run')
                  and regressor.mask.numel() <= 256)
-    if eligible and not on_device:
+    if eligible and not on_device and group is None:      # (the host-shadow closure is single-rank; shards take the generic closure)
         rev = None
         if w_sym_reg > 0.0:
             from .model_utils import precompute_symmreg_r
@@ -1008,6 +1029,10 @@ def train_SIGED_lbfgs(
                     key, v = 'test_loss_sindy_z', regressor.mse_loss(z, autoencoder.compute_dz(x, dx)).item()
                 elif value is not None:
                     key, v = 'test_loss_sindy_x', value
+                elif group is not None:                                                # this rank's shard -> the batch mean
+                    n_loc = float(x.numel())
+                    red = allreduce_sums([regressor.mse_loss(x, dx) * n_loc, torch.tensor(n_loc, device=x.device)], [], group)
+                    key, v = 'test_loss_sindy_x', (red[0] / red[1]).item()
                 else:
                     key, v = 'test_loss_sindy_x', regressor.mse_loss(x, dx).item()
             for _ in range(n):

@@ -170,3 +170,30 @@ def compiled(d, order, flags=0):
 def only_compiled(cases):
     """Filter a parametrize list whose entries start with (d, order, ...)."""
     return [c for c in cases if compiled(c[0], c[1])]
+
+
+CONFIG2_AE = dict(ae_arch="mlp", input_dim=2, hidden_dim=512, latent_dim=2, n_layers=5, n_comps=2, activation="ReLU",
+                  activation_args=[], batch_norm=True, ortho_ae=True)
+CONFIG2_GEN = dict(repr="(2,1,2)", group_idx="0", sigma_init=1, gan_st_thres=0.3, keep_center=True, n_comps=2)
+
+
+def make_config2(S, dev):
+    """BASELINE config[2] (lv/noise99_eq_isymreg.cfg) at full size: (x, dx) (20 000, 2), frozen autoencoder, generator."""
+    from symode_amd.autoencoder import AutoEncoder
+    from symode_amd.lie import LieGenerator
+    x, dx = S.data.gen_data("lv", 200, dt=0.002, num_steps=10000, noise=0.99, smoothing="gp", seed=0, device=dev)
+    x, dx = x.reshape(-1, 2), dx.reshape(-1, 2)
+    rows = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(0))[:20000].to(dev)
+    x, dx = x[rows].contiguous(), dx[rows].contiguous()
+    torch.manual_seed(11)
+    ae = AutoEncoder(**CONFIG2_AE).to(dev)
+    gen = LieGenerator(device=dev, **CONFIG2_GEN).to(dev)
+    ae.train()
+    with torch.no_grad():
+        for k in range(4):
+            ae(torch.stack([x[k::4], x[k::4] + 0.1 * dx[k::4]], dim=1))
+    ae.eval()
+    gen.eval()
+    for p in list(ae.parameters()) + list(gen.parameters()):
+        p.requires_grad = False
+    return x, dx, ae, gen

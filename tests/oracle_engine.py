@@ -38,6 +38,19 @@ class OracleEngine:
             gx, gw = torch.autograd.grad(out, (xx, w), g)
         return (gx if need_grad_x else None), gw
 
+    def jvp_vjp(self, x, v, g_out, g_jv, xi, mask, order, flags=0):
+        """reverse mode of forward_jvp: (grad_x, grad_v, grad_xi)"""
+        m = torch.ones_like(xi) if mask is None else mask
+        with torch.enable_grad():
+            xx = x.detach().clone().requires_grad_(True)
+            vv = v.detach().clone().requires_grad_(True)
+            w = xi.detach().clone().requires_grad_(True)
+            out, jv = torch.autograd.functional.jvp(lambda a: O.forward(a, w, m, order, *_fl(flags)), xx, vv, create_graph=True)
+            s = (jv * g_jv).sum() + (0.0 if g_out is None else (out * g_out).sum())
+            gx, gv, gw = torch.autograd.grad(s, (xx, vv, w), allow_unused=True)
+        z = torch.zeros_like
+        return (z(x) if gx is None else gx), (z(v) if gv is None else gv), (z(xi) if gw is None else gw)
+
     def odeint(self, x, xi, mask, order, flags, n_steps, dt, method="euler"):
         m = torch.ones_like(xi) if mask is None else mask
         f = lambda a: O.forward(a, xi, m, order, *_fl(flags))  # noqa: E731

@@ -79,3 +79,87 @@ def test_config1_dosc_order5_constrained_lbfgs_sweep_two_ranks_equals_one_rank(t
     assert np.array_equal(one != 0, two != 0)                                   # identical masks
     # un-line-searched L-BFGS amplifies the fp32 summation-order difference of the shards up to its stopping ball
     assert np.allclose(one, two, rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config[2]'s closure on point shards (model_utils.py:56-62, 118-121): the relative
+# regularisers are ratios of batch means, so per generator the numerator, the denominator and their d/dXi are summed
+# locally and cross the ranks in ONE packed all-reduce; ratio and quotient-rule gradient are formed after it.
+# ---------------------------------------------------------------------------------------------------------------------
+def _config2_closure(MU, reg, kind, ae, gen, x, dx, group=None):
+    fn = MU.symmreg_i if kind == "i" else MU.symmreg_f
+    flow = MU._EulerFlow(reg, 0.1, 0.01)                                   # K = 10 Euler steps (lv/noise99_eq_isymreg.cfg)
+    reg.Xi.grad = None
+    x_fx = torch.stack([x, flow(x)], dim=1)
+    mse = reg.mse_loss(x, dx)
+    if group is None:
+        sym = fn(x_fx, ae, gen, f=flow, x_const=x, require_grad=True)
+    else:
+        n_loc = float(x.numel())
+        sym, red = fn(x_fx, ae, gen, f=flow, x_const=x, require_grad=True, group=group,
+                      also=[mse * n_loc, torch.tensor(n_loc, device=x.device)])
+        mse = red[0] / red[1]
+    (mse + 0.1 * sym).backward()
+    return np.array([mse.item(), sym.item()]), reg.Xi.grad.detach().cpu().numpy().copy()
+
+
+def _config2_rank(rank, world, port, blob_path, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import symode_amd
+    from symode_amd import model_utils as MU
+    from symode_amd.autoencoder import AutoEncoder
+    from symode_amd.lie import LieGenerator
+    from tests.helpers import CONFIG2_AE, CONFIG2_GEN
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"
+    blob = torch.load(blob_path, weights_only=True)
+    ae = AutoEncoder(**CONFIG2_AE).to(dev)
+    gen = LieGenerator(device=dev, **CONFIG2_GEN).to(dev)
+    ae.load_state_dict(blob["ae"])
+    gen.load_state_dict(blob["gen"])
+    ae.eval()
+    gen.eval()
+    for p in list(ae.parameters()) + list(gen.parameters()):
+        p.requires_grad = False
+    x, dx = blob["x"].to(dev), blob["dx"].to(dev)
+    n = x.shape[0]
+    cut = n // 2 + 12                                                    # uneven shards of whole 16-byte chunks
+    lo, hi = (0, cut) if rank == 0 else (cut, n)
+    xs, dxs = x[lo:hi].contiguous(), dx[lo:hi].contiguous()
+    reg = symode_amd.SINDyRegression(2, 2, False, True, threshold=0.15, device=dev)
+    reg.Xi.data = blob["Xi0"].to(dev)
+    res = {}
+    for kind in ("i", "f"):
+        res[f"{kind}_vals"], res[f"{kind}_grad"] = _config2_closure(MU, reg, kind, ae, gen, xs, dxs, group=dist.group.WORLD)
+    np.savez(os.path.join(out_dir, f"config2_rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config2_relative_regulariser_closure_two_ranks_equals_one_rank(tmp_path):
+    """20 000 points, K = 10, 512 x 5 autoencoder: value and gradient of MSE + 0.1 * symmreg_{i,f} from two point shards
+    (HIP engine, both ranks on cuda:0, gloo) against the one-process closure -- 1e-5."""
+    import symode_amd
+    from symode_amd import model_utils as MU
+    from tests.helpers import make_config2
+    dev = "cuda:0"
+    x, dx, ae, gen = make_config2(symode_amd, dev)
+    torch.manual_seed(3)
+    Xi0 = torch.randn(2, 8) * 0.3
+    reg = symode_amd.SINDyRegression(2, 2, False, True, threshold=0.15, device=dev)
+    reg.Xi.data = Xi0.to(dev)
+    one = {kind: _config2_closure(MU, reg, kind, ae, gen, x, dx) for kind in ("i", "f")}
+    blob = tmp_path / "config2.pt"
+    torch.save({"x": x.cpu(), "dx": dx.cpu(), "Xi0": Xi0, "ae": {k: v.cpu() for k, v in ae.state_dict().items()},
+                "gen": {k: v.cpu() for k, v in gen.state_dict().items()}}, blob)
+    mp.spawn(_config2_rank, args=(2, _free_port(), str(blob), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(tmp_path / f"config2_rank{r}.npz") for r in range(2)]
+    for kind in ("i", "f"):
+        vals, grad = one[kind]
+        assert np.array_equal(r0[f"{kind}_vals"], r1[f"{kind}_vals"]) and np.array_equal(r0[f"{kind}_grad"], r1[f"{kind}_grad"])
+        e_val = np.abs(r0[f"{kind}_vals"] - vals) / np.abs(vals)
+        e_grad = np.abs(r0[f"{kind}_grad"] - grad).max() / np.abs(grad).max()
+        print(f"config2 sym_reg_type {kind}, 2 ranks vs 1: mse {e_val[0]:.2e}, regulariser {e_val[1]:.2e}, gradient {e_grad:.2e}")
+        assert e_val.max() <= 1e-5 and e_grad <= 1e-5, (kind, e_val, e_grad)

@@ -44,26 +44,8 @@ def config2(S):
     subsample, a frozen 512 x 5 orthogonal + batch-norm autoencoder with n_comps 2 and the (2,1,2) generator.  The
     authors' LaLiGAN checkpoint is not shipped, so the autoencoder is a seeded random one whose BatchNorm statistics
     were set by a few training-mode passes over the data."""
-    from symode_amd.autoencoder import AutoEncoder
-    from symode_amd.lie import LieGenerator
-    x, dx = S.data.gen_data("lv", 200, dt=0.002, num_steps=10000, noise=0.99, smoothing="gp", seed=0, device=DEV)
-    x, dx = x.reshape(-1, 2), dx.reshape(-1, 2)
-    rows = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(0))[:20000].to(DEV)
-    x, dx = x[rows].contiguous(), dx[rows].contiguous()
-    torch.manual_seed(11)
-    ae = AutoEncoder(ae_arch="mlp", input_dim=2, hidden_dim=512, latent_dim=2, n_layers=5, n_comps=2, activation="ReLU",
-                     activation_args=[], batch_norm=True, ortho_ae=True).to(DEV)
-    gen = LieGenerator(repr="(2,1,2)", group_idx="0", sigma_init=1, gan_st_thres=0.3, keep_center=True, n_comps=2,
-                       device=DEV).to(DEV)
-    ae.train()
-    with torch.no_grad():
-        for k in range(4):
-            ae(torch.stack([x[k::4], x[k::4] + 0.1 * dx[k::4]], dim=1))
-    ae.eval()
-    gen.eval()
-    for p in list(ae.parameters()) + list(gen.parameters()):
-        p.requires_grad = False
-    return x, dx, ae, gen
+    from tests.helpers import make_config2
+    return make_config2(S, DEV)
 
 
 @pytest.mark.parametrize("split", [True, False], ids=["x_const", "whole_batch"])
