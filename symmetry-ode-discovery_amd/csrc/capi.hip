@@ -84,6 +84,8 @@ inline int gram_valu_grid(long n, long S, int d) {
 //   1 M             vjp 18.2 / 13.8 / 13.2 / 16.8 / 16.7    jvp_vjp 31.5 / 21.0 / 17.2 / 21.3 / 21.5
 //   8 M             vjp 181 / 103 / 61 / 45.8 / 48.8        jvp_vjp 205 / 112 / 70.2 / 79.3 / 118
 //   64 M            vjp 1461 / 780 / 436 / 310 / 289        jvp_vjp 1605 / 841 / 495 / 572 / 561
+// (round 3: with the register-ring pipelines the optimum moved to ONE workgroup per CU from 4 M points up --
+//  profiles/r03_stream_ab.txt, 64 .. 1024 workgroups at 125 000 .. 64 M points)
 // hence a cap per size class: <= 300 K points, <= 2 M, <= 16 M, beyond.  SYMODE_REDUCE_GRID overrides it for tuning runs.
 inline int single_problem_grid(int gx, long n, int c_small, int c_mid, int c_large, int c_huge) {
     static const int env = getenv("SYMODE_REDUCE_GRID") ? atoi(getenv("SYMODE_REDUCE_GRID")) : 0;
@@ -208,7 +210,9 @@ int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, i
     // a single latency-bound problem: the last workgroup adds gx partial rows alone, so fewer, longer workgroups win
     // (SYMODE_SMALL_GRID overrides the cap for tuning runs; 0 = no cap)
     if (n_problems == 1) {
-        const int cap = small_grid_cap(n, false);
+        // (order 4-5 libraries are as arithmetic-heavy as the regulariser closures: 64 M points at order 5, 240 us at 256
+        //  workgroups, 184 at 512 -- profiles/r03_closure_ab.txt)
+        const int cap = small_grid_cap(n, ops->d * ops->p > 32);
         if (cap > 0 && gx > cap) gx = cap;
     }
     return (int)ops->loss_grad(x, dx, n_problems, n, xi, mask, inv_count, loss_out, grad_out, (double*)workspace, gx,
@@ -246,7 +250,7 @@ int symode_symreg_linear(const float* z, long n, int d, int order, int flags, co
     if (!z || !xi || !loss_out || !grad_out || (n_gen > 0 && !L)) return SYMODE_E_NULLPTR;
     if (misaligned(z, 4) || misaligned(xi, 4) || misaligned(mask, 4) || misaligned(L, 4)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 512, 1024);
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 512, 512);      // r03_stream_ab.txt
     return (int)ops->symreg_linear(z, n, xi, mask, L, n_gen, loss_out, grad_out, (double*)workspace, gx,
                                    (hipStream_t)stream);
 }
@@ -322,8 +326,9 @@ int symode_vjp(const float* x, const float* g, long n, int d, int order, int fla
         misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = grad_x ? single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 512, 1024)
-                          : single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 128, 512, 512);
+    // register ring of 3 chunks per lane: one workgroup per CU streams best from 4 M points up (round 3,
+    // profiles/r03_stream_ab.txt: 64 M points 262 us at 256 workgroups against 321 at 1024; without grad_x 152 against 188)
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 64, 128, 256, 256);
     return (int)ops->vjp(x, g, n, xi, mask, grad_x, grad_xi, (double*)workspace, gx, (hipStream_t)stream);
 }
 
@@ -349,7 +354,7 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
         misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 256, 256);
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 256, 256);      // ring of 3: r03_stream_ab.txt
     return (int)ops->jvp_vjp(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, grad_xi, (double*)workspace, gx,
                              (hipStream_t)stream);
 }

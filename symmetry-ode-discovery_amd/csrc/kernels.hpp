@@ -125,11 +125,18 @@ inline bool vec_ok(const void* p, long n, int d, long S) {
 #ifndef SYMODE_ROWS_XI_SGPR
 #define SYMODE_ROWS_XI_SGPR 1       // loss_grad_rows_kernel: its row of Xi in SGPRs (1) or VGPRs (0); measured 555 vs 587 us at p = 35
 #endif
+// D = 3 libraries with sine / exp columns stream point by point, not in 16-byte chunks: a chunk is four points, and four
+// interleaved copies of a per-point body with inlined sinf / expf want more than the register file (odeint, sine + exp:
+// 248 VGPRs and 480 bytes of scratch per lane).  Those kernels are bound by the transcendentals, not by how the 12-byte
+// points arrive; the per-point path is the one every kernel already has for unaligned bases.
+template <class Lib>
+constexpr bool chunked_stream = !((Lib::D == 3) && (Lib::SINE || Lib::EXP));
+
 constexpr int VGPR_XI_MAX = 48;     // up to here the masked coefficients simply stay in VGPRs (see load_xi)
 constexpr int SGPR_XI_MAX = 64;     // VGPR_XI_MAX < D*P <= this: Xi in SGPRs (the wave has ~100 of them: d = 3 order 3, d = 4 order 2)
 
 // Masked coefficients of problem s into registers (uniform across the block -> scalar loads).
-template <class Lib, int SGPR_FROM = VGPR_XI_MAX + 1>
+template <class Lib, int SGPR_FROM = VGPR_XI_MAX + 1, int SGPR_TO = SGPR_XI_MAX>
 __device__ __forceinline__ void load_xi(const float* __restrict__ xi, const float* __restrict__ mask, long s,
                                         float (&w)[Lib::D * Lib::P]) {
     constexpr int DP = Lib::D * Lib::P;
@@ -146,7 +153,7 @@ __device__ __forceinline__ void load_xi(const float* __restrict__ xi, const floa
     // Mid-size libraries (48 < D*P <= 64: d = 3 order 3, d = 4 order 2) are short of registers instead, so their
     // coefficients -- wave-uniform values -- go back to the scalar file and the D*P VGPRs become occupancy (6.4 -> 6.8 TB/s).
     // (SGPR_FROM: kernels with more per-point state than K1 move the coefficients out of the vector file earlier.)
-    if constexpr (DP >= SGPR_FROM && DP <= SGPR_XI_MAX) {
+    if constexpr (DP >= SGPR_FROM && DP <= SGPR_TO) {
 #pragma unroll
         for (int i = 0; i < DP; ++i)
             w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[i])));
@@ -220,6 +227,7 @@ template <class Lib>
 __global__ __launch_bounds__(BLOCK) void forward_kernel(const float* __restrict__ x, long N, bool vec,
                                                         const float* __restrict__ xi, const float* __restrict__ mask,
                                                         float* __restrict__ out) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
     float w[D * Lib::P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -230,8 +238,7 @@ __global__ __launch_bounds__(BLOCK) void forward_kernel(const float* __restrict_
         N, vec, [&](long c, Ops& o) { load_chunk<D>(x, c, o.x); },
         [&](long c, Ops& o) {
             float h[PPT][D];
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) rhs<Lib>(w, o.x[i], h[i]);
+            each_point<PPT>([&](auto i) { rhs<Lib>(w, o.x[i], h[i]); });
             store_chunk_nt<D>(out, c, h);
         },
         [&](long n) {
@@ -305,6 +312,7 @@ template <class Lib>
 __global__ __launch_bounds__(BLOCK) void odeint_kernel(const float* __restrict__ x, long N, bool vec,
                                                        const float* __restrict__ xi, const float* __restrict__ mask,
                                                        int n_steps, float dt, int method, float* __restrict__ out) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
     float w[D * Lib::P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -314,8 +322,7 @@ __global__ __launch_bounds__(BLOCK) void odeint_kernel(const float* __restrict__
     for_each_chunk2<D, BLOCK, Ops>(
         N, vec, [&](long c, Ops& o) { load_chunk<D>(x, c, o.x); },
         [&](long c, Ops& o) {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) integrate<Lib>(w, o.x[i], n_steps, dt, method);
+            each_point<PPT>([&](auto i) { integrate<Lib>(w, o.x[i], n_steps, dt, method); });
             store_chunk_nt<D>(out, c, o.x);
         },
         [&](long n) {
@@ -404,9 +411,20 @@ __device__ __forceinline__ void combine_rows(const double* __restrict__ src, int
     }
 }
 
+// `lds`: the block reduction's staging area, reduce_lds_floats(BLOCK) floats.  The second form lets a kernel that holds
+// a large LDS region of its own during the point loop (the Euler reverse sweep's state column) hand that region over
+// instead of adding 17 KB per workgroup to it; the caller's threads are past their last access to it (barrier inside).
+template <int NACC>
+__device__ __forceinline__ void emit_partials_in(float (&acc)[NACC], double* __restrict__ part, const Finish& fin, float* lds);
+
 template <int NACC>
 __device__ __forceinline__ void emit_partials(float (&acc)[NACC], double* __restrict__ part, const Finish& fin) {
     __shared__ float lds[reduce_lds_floats(BLOCK)];
+    emit_partials_in<NACC>(acc, part, fin, lds);
+}
+
+template <int NACC>
+__device__ __forceinline__ void emit_partials_in(float (&acc)[NACC], double* __restrict__ part, const Finish& fin, float* lds) {
     __shared__ unsigned last_flag;
     const long s = blockIdx.y;
     const int G = gridDim.x;
@@ -488,6 +506,7 @@ template <class Lib, int VARIANT>
 __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, const float* __restrict__ dx, long N, bool vec,
                                                const float* __restrict__ xi, const float* __restrict__ mask,
                                                double* __restrict__ ws, const Finish& fin, const bool SEGMENTED) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
     constexpr bool NT = (VARIANT == 4 || VARIANT == 5 || VARIANT == 7);
     const long s = blockIdx.y;
@@ -517,8 +536,7 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
         float xp[PPT][D], yp[PPT][D];
         unpack_chunk<D>(vx, xp);
         unpack_chunk<D>(vy, yp);
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) one(xp[i], yp[i]);
+        each_point<PPT>([&](auto i) { one(xp[i], yp[i]); });
     };
     auto point = [&](long n) {
         float xp[D], yp[D];
@@ -726,6 +744,7 @@ __device__ __forceinline__ void loss_grad_body_packed(const float* __restrict__ 
                                                       bool vec, const float* __restrict__ xi,
                                                       const float* __restrict__ mask, double* __restrict__ ws,
                                                       const Finish& fin, const bool SEGMENTED) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
     constexpr int JP = D / 2;
     constexpr bool ODD = (D % 2) != 0;
@@ -891,6 +910,7 @@ __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restric
                                                           long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, double* __restrict__ ws,
                                                           Finish fin, bool segmented) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     if constexpr (VARIANT == 6)
         loss_grad_body_packed<Lib>(x, dx, N, vec, xi, mask, ws, fin, segmented);
     else
@@ -902,15 +922,16 @@ __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restric
 //   u = Xi_m (J_Theta(z) L z) - L (Xi_m Theta(z));  loss = sum |u|^2 over points and generators;
 //   dloss/dXi[j,k] = 2 sum ( u_j dth_k - (L^T u)_j th_k ).
 // ---------------------------------------------------------------------------------------
-template <class Lib>
-__global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __restrict__ z, long N, bool vec,
+template <class Lib, int R = 4, int XI_SGPR_FROM = VGPR_XI_MAX + 1, int MINW = 1>
+__global__ __launch_bounds__(BLOCK, MINW) void symreg_linear_kernel(const float* __restrict__ z, long N, bool vec,
                                                               const float* __restrict__ xi,
                                                               const float* __restrict__ mask,
                                                               const float* __restrict__ Lg, int n_gen,
                                                               double* __restrict__ ws, Finish fin) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NACC = 1 + D * P;
     float w[D * P];
-    load_xi<Lib>(xi, mask, 0, w);
+    load_xi<Lib, XI_SGPR_FROM>(xi, mask, 0, w);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
@@ -971,11 +992,10 @@ __global__ __launch_bounds__(BLOCK) void symreg_linear_kernel(const float* __res
     // 8 bytes per point against ~115 vector instructions: the stream is thin, but a wave that waits out every miss
     // idles its SIMD -- four chunks per lane in flight (points.hpp, for_each_chunk_ring)
     const float* const arrs[1] = {z};
-    for_each_chunk_ring<D, BLOCK, 4, 1>(
+    for_each_chunk_ring<D, BLOCK, R, 1>(
         N, vec, arrs,
-        [&](long, const float (&zp)[1][PPT][D]) {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) one(zp[0][i]);
+        [&](long, float (&zp)[1][PPT][D]) {
+            each_point<PPT>([&](auto i) { one(zp[0][i]); });
         },
         [&](long n) {
             float zp[D];
@@ -1003,13 +1023,14 @@ struct JChunk {
 // MSE = true: the whole closure of the reversed-regulariser runs in ONE pass -- the residual r = h(x) - dx shares
 // Theta(x) and h(x) with the regulariser, x is read once (40 instead of 16 + 32 bytes per point at D = 2, n_g = 1):
 //   sums[0] = sum r^2, sums[1] = sum_g sum u^2,  grad = d( sums[0] + w_sym sums[1] ) / dXi  (both under the same 1/(N D)).
-template <class Lib, bool MSE>
+template <class Lib, bool MSE, int RING = 2>
 __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                                 const float* __restrict__ gx,
                                                                 const float* __restrict__ jgx, int n_g, long N, bool vec,
                                                                 const float* __restrict__ xi,
                                                                 const float* __restrict__ mask, float w_sym,
                                                                 double* __restrict__ ws, Finish fin) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, NL = MSE ? 2 : 1, NACC = NL + D * P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV,
                   NVJ = JChunk<D>::NV, SYM0 = NL - 1;
     const long s = blockIdx.y;
@@ -1018,7 +1039,9 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
     const float* gs = gx + s * (long)n_g * N * D;
     const float* js = jgx + s * (long)n_g * N * D * D;
     float w[D * P];
-    load_xi<Lib, 32>(xi, mask, s, w);          // two libraries per point live here: Xi in SGPRs from d*p = 32 (3 waves/SIMD at order 5)
+    // two libraries per point live here: Xi in SGPRs from d*p = 32 (3 waves/SIMD at order 5) -- and up to 80, the d = 3
+    // order-3 libraries with sine / exp columns (69-78 coefficients would otherwise sit in VGPRs beside 70-79 sums)
+    load_xi<Lib, 32, 80>(xi, mask, s, w);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
@@ -1070,9 +1093,9 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
         }
     };
     // the chunk's points against group element g, operands already in registers
-    auto chunk_g = [&](const float (&th)[PPT][P], const float (&h)[PPT][D], const float4 (&vg)[NV], const float4 (&vj)[NVJ],
-                       const float (&extra)[PPT][D]) {
-        float gp[PPT][D], jf[NVJ * 4];
+    auto chunk_g = [&](float (&th)[PPT][P], float (&h)[PPT][D], const float4 (&vg)[NV], const float4 (&vj)[NVJ],
+                       float (&extra)[PPT][D]) {
+        float gp[PPT][D], jf[NVJ * 4], J[PPT][D * D];
         unpack_chunk<D>(vg, gp);
 #pragma unroll
         for (int i = 0; i < NVJ; ++i) {
@@ -1082,12 +1105,8 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
             jf[4 * i + 3] = vj[i].w;
         }
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            float J[D * D];
-#pragma unroll
-            for (int e = 0; e < D * D; ++e) J[e] = jf[i * D * D + e];
-            one(th[i], h[i], gp[i], J, extra[i]);
-        }
+        for (int e = 0; e < PPT * D * D; ++e) J[e / (D * D)][e % (D * D)] = jf[e];
+        each_point<PPT>([&](auto i) { one(th[i], h[i], gp[i], J[i], extra[i]); });
     };
     auto point = [&](long n) {
         float xp[D], th[P], h[D], r[D], zero[D];
@@ -1116,16 +1135,55 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
     auto eval_x = [&](const float4 (&vx)[NV], float (&th)[PPT][P], float (&h)[PPT][D]) {
         float xp[PPT][D];
         unpack_chunk<D>(vx, xp);
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
+        each_point<PPT>([&](auto i) {
             Lib::eval(xp[i], th[i]);
             apply_xi<Lib>(w, th[i], h[i]);
-        }
+        });
     };
 
     const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
     // one chunk: its points' Theta(x), h(x) are formed once and live only while this chunk's group elements are visited
     auto chunk_all = [&](long c, const float4 (&vx)[NV], const float4 (&vy)[NV], const float4 (&vg)[NV], const float4 (&vj)[NVJ]) {
+        if constexpr (D == 3) {
+            // four points per chunk: Theta(x), h(x) of ALL of them (4 P + 12 registers) do not fit beside the sums -- point by
+            // point instead, Theta(x) re-evaluated for every further group element (same values, same order of every sum)
+            float xp[PPT][D], yp[PPT][D];
+            unpack_chunk<D>(vx, xp);
+            if constexpr (MSE) unpack_chunk<D>(vy, yp);
+            auto group = [&](const float4 (&ug)[NV], const float4 (&uj)[NVJ], bool first) {
+                float gp[PPT][D], jf[NVJ * 4], J[PPT][D * D];
+                unpack_chunk<D>(ug, gp);
+#pragma unroll
+                for (int i = 0; i < NVJ; ++i) {
+                    jf[4 * i + 0] = uj[i].x;
+                    jf[4 * i + 1] = uj[i].y;
+                    jf[4 * i + 2] = uj[i].z;
+                    jf[4 * i + 3] = uj[i].w;
+                }
+#pragma unroll
+                for (int e = 0; e < PPT * D * D; ++e) J[e / (D * D)][e % (D * D)] = jf[e];
+                auto body = [&](auto i) {
+                    float th[P], h[D], r[D];
+                    Lib::eval(xp[i], th);
+                    apply_xi<Lib>(w, th, h);
+#pragma unroll
+                    for (int j = 0; j < D; ++j) r[j] = 0.0f;
+                    if constexpr (MSE) {
+                        if (first) resid(h, yp[i], r);
+                    }
+                    one(th, h, gp[i], J[i], r);
+                };
+                each_point<PPT>(body);
+            };
+            group(vg, vj, true);
+            for (int g = 1; g < n_g; ++g) {
+                float4 ng[NV], nj[NVJ];
+                load_chunk_raw<D, true>(gs + (long)g * N * D, c, ng);
+                load_j(js + (long)g * N * D * D, c, nj);
+                group(ng, nj, false);
+            }
+            return;
+        }
         float th[PPT][P], h[PPT][D], r[PPT][D], zero[PPT][D];
         eval_x(vx, th, h);
 #pragma unroll
@@ -1135,8 +1193,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
         if constexpr (MSE) {
             float yp[PPT][D];
             unpack_chunk<D>(vy, yp);
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) resid(h[i], yp[i], r[i]);
+            each_point<PPT>([&](auto i) { resid(h[i], yp[i], r[i]); });
         }
         chunk_g(th, h, vg, vj, r);
         for (int g = 1; g < n_g; ++g) {
@@ -1147,30 +1204,44 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
         }
     };
     if (vec && n_g > 0) {
+        // register ring: RING chunks of x, (dx,) g(x), J_g of the first group element in flight per lane, a slot refilled
+        // as soon as its chunk has been consumed (closure_ab: one 2^26-point problem 334 -> 325 us at order 3, the fused
+        // closure at order 5 470 -> 442 us; the batched bench shape is VALU / HBM co-limited either way)
+        constexpr int NVT = (MSE ? 3 : 2) * NV + NVJ, OY = NV, OG = (MSE ? 2 : 1) * NV, OJ = OG + NV;
         const long nchunks = N / PPT;
-        long c = tid;
-        for (; c + nthreads < nchunks; c += 2 * nthreads) {
-            // both chunks' x, (dx,) g(x), J_g of the first group element in flight before any arithmetic
-            float4 ax[NV], bx[NV], ay[NV], by[NV], ag[NV], bg[NV], aj[NVJ], bj[NVJ];
-            load_chunk_raw<D, true>(xs, c, ax);
-            if constexpr (MSE) load_chunk_raw<D, true>(ys, c, ay);
-            load_chunk_raw<D, true>(gs, c, ag);
-            load_j(js, c, aj);
-            load_chunk_raw<D, true>(xs, c + nthreads, bx);
-            if constexpr (MSE) load_chunk_raw<D, true>(ys, c + nthreads, by);
-            load_chunk_raw<D, true>(gs, c + nthreads, bg);
-            load_j(js, c + nthreads, bj);
-            chunk_all(c, ax, ay, ag, aj);
-            chunk_all(c + nthreads, bx, by, bg, bj);
-        }
-        if (c < nchunks) {
-            float4 ax[NV], ay[NV], ag[NV], aj[NVJ];
-            load_chunk_raw<D, true>(xs, c, ax);
-            if constexpr (MSE) load_chunk_raw<D, true>(ys, c, ay);
-            load_chunk_raw<D, true>(gs, c, ag);
-            load_j(js, c, aj);
-            chunk_all(c, ax, ay, ag, aj);
-        }
+        chunk_ring<(D == 3 ? 1 : RING), NVT>(       // D = 3: a slot is 15-18 vectors (60-72 VGPRs), one chunk in flight
+            nchunks, tid, nthreads,
+            [&](long q, float4 (&slot)[NVT]) {
+                float4 tx[NV], tg[NV], tj[NVJ];
+                load_chunk_raw<D, true>(xs, q, tx);
+                load_chunk_raw<D, true>(gs, q, tg);
+                load_j(js, q, tj);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    slot[i] = tx[i];
+                    slot[OG + i] = tg[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NVJ; ++i) slot[OJ + i] = tj[i];
+                if constexpr (MSE) {
+                    float4 ty[NV];
+                    load_chunk_raw<D, true>(ys, q, ty);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) slot[OY + i] = ty[i];
+                }
+            },
+            [&](long c, const float4 (&slot)[NVT]) {
+                float4 ax[NV], ay[NV], ag[NV], aj[NVJ];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    ax[i] = slot[i];
+                    ay[i] = MSE ? slot[OY + i] : slot[i];
+                    ag[i] = slot[OG + i];
+                }
+#pragma unroll
+                for (int i = 0; i < NVJ; ++i) aj[i] = slot[OJ + i];
+                chunk_all(c, ax, ay, ag, aj);
+            });
         const long n = nchunks * PPT + tid;
         if (n < N) point(n);
     } else {
@@ -1184,10 +1255,11 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
 //   grad_x[n] = J_Theta(x_n)^T (Xi_m^T g_n)           (optional)
 //   grad_xi   = (sum_n g_n Theta(x_n)^T) * mask        (through the partial-sum epilogue)
 // ---------------------------------------------------------------------------------------
-template <class Lib>
+template <class Lib, bool GX, int R = 3>
 __global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x, const float* __restrict__ g, long N, bool vec,
                                                     const float* __restrict__ xi, const float* __restrict__ mask,
                                                     float* __restrict__ grad_x, double* __restrict__ ws, Finish fin) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -1201,7 +1273,7 @@ __global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x,
         for (int j = 0; j < D; ++j)
 #pragma unroll
             for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(gp[j], th[k], acc[1 + j * P + k]);
-        if (grad_x != nullptr) {
+        if constexpr (GX) {
             float bar[P];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
@@ -1213,27 +1285,22 @@ __global__ __launch_bounds__(BLOCK) void vjp_kernel(const float* __restrict__ x,
             Lib::vjp(xp, th, bar, bx);
         }
     };
-    struct Ops {
-        float x[PPT][D], g[PPT][D];
-    };
-    for_each_chunk2<D, BLOCK, Ops>(
-        N, vec,
-        [&](long c, Ops& o) {
-            load_chunk<D>(x, c, o.x);
-            load_chunk<D>(g, c, o.g);
-        },
-        [&](long c, Ops& o) {
+    // a reduction launch: few long-lived workgroups, so the wave's own run-ahead hides the latency (three chunks of x
+    // and g in flight per lane; the grad_x stores of a chunk sit in the same in-order queue as the loads behind them)
+    const float* const arrs[2] = {x, g};
+    for_each_chunk_ring<D, BLOCK, R, 2>(
+        N, vec, arrs,
+        [&](long c, float (&o)[2][PPT][D]) {
             float bx[PPT][D];
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) one(o.x[i], o.g[i], bx[i]);
-            if (grad_x != nullptr) store_chunk_nt<D>(grad_x, c, bx);
+            each_point<PPT>([&](auto i) { one(o[0][i], o[1][i], bx[i]); });
+            if constexpr (GX) store_chunk_nt<D>(grad_x, c, bx);
         },
         [&](long n) {
             float xp[D], gp[D], bx[D];
             load_point<D>(x, n, xp);
             load_point<D>(g, n, gp);
             one(xp, gp, bx);
-            if (grad_x != nullptr) store_point<D>(grad_x, n, bx);
+            if constexpr (GX) store_point<D>(grad_x, n, bx);
         });
     emit_partials<NACC>(acc, ws, fin);
 }
@@ -1244,6 +1311,7 @@ __global__ __launch_bounds__(BLOCK) void forward_jvp_kernel(const float* __restr
                                                             long N, bool vec, const float* __restrict__ xi,
                                                             const float* __restrict__ mask, float* __restrict__ out,
                                                             float* __restrict__ jv) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT;
     float w[D * P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -1264,8 +1332,7 @@ __global__ __launch_bounds__(BLOCK) void forward_jvp_kernel(const float* __restr
         },
         [&](long c, Ops& o) {
             float h[PPT][D], t[PPT][D];
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) one(o.x[i], o.v[i], h[i], t[i]);
+            each_point<PPT>([&](auto i) { one(o.x[i], o.v[i], h[i], t[i]); });
             if (out != nullptr) store_chunk_nt<D>(out, c, h);
             store_chunk_nt<D>(jv, c, t);
         },
@@ -1280,16 +1347,17 @@ __global__ __launch_bounds__(BLOCK) void forward_jvp_kernel(const float* __restr
 }
 
 // Reverse mode of forward_jvp_kernel: upstream g_out on out (may be null) and g_jv on jv.
-template <class Lib>
+template <class Lib, bool GO = true, int R = 3>
 __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                         const float* __restrict__ g_out,
                                                         const float* __restrict__ g_jv, long N, bool vec,
                                                         const float* __restrict__ xi, const float* __restrict__ mask,
                                                         float* __restrict__ grad_x, float* __restrict__ grad_v,
                                                         double* __restrict__ ws, Finish fin) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT;
     float w[D * P];
-    load_xi<Lib>(xi, mask, 0, w);
+    load_xi<Lib, VGPR_XI_MAX + 1, 80>(xi, mask, 0, w);   // (th, dth, bar, dbar live per point: Xi leaves the vector file up to 80 coefficients)
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
@@ -1311,46 +1379,44 @@ __global__ __launch_bounds__(BLOCK) void jvp_vjp_kernel(const float* __restrict_
         }
         Lib::vjp_of_jvp(xp, vp, th, dth, bar, dbar, bx, bv);
     };
-    struct Ops {
-        float x[PPT][D], v[PPT][D], go[PPT][D], gt[PPT][D];
+    // GO: an upstream gradient on `out` exists (g_out != nullptr); else its chunk is not loaded at all
+    constexpr int NA = GO ? 4 : 3;
+    auto chunk = [&](long c, float (&o)[NA][PPT][D]) {
+        float bx[PPT][D], bv[PPT][D], zero[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) zero[j] = 0.0f;
+        auto body = [&](auto i) {
+            if constexpr (GO)
+                one(o[0][i], o[1][i], o[NA - 1][i], o[2][i], bx[i], bv[i]);
+            else
+                one(o[0][i], o[1][i], zero, o[2][i], bx[i], bv[i]);
+        };
+        each_point<PPT>(body);
+        store_chunk_nt<D>(grad_x, c, bx);
+        store_chunk_nt<D>(grad_v, c, bv);
     };
-    for_each_chunk2<D, BLOCK, Ops>(
-        N, vec,
-        [&](long c, Ops& o) {
-            load_chunk<D>(x, c, o.x);
-            load_chunk<D>(v, c, o.v);
-            load_chunk<D>(g_jv, c, o.gt);
-            if (g_out != nullptr) {
-                load_chunk<D>(g_out, c, o.go);
-            } else {
+    auto point = [&](long n) {
+        float xp[D], vp[D], go[D], gt[D], bx[D], bv[D];
+        load_point<D>(x, n, xp);
+        load_point<D>(v, n, vp);
+        load_point<D>(g_jv, n, gt);
+        if constexpr (GO) {
+            load_point<D>(g_out, n, go);
+        } else {
 #pragma unroll
-                for (int i = 0; i < PPT; ++i)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) o.go[i][j] = 0.0f;
-            }
-        },
-        [&](long c, Ops& o) {
-            float bx[PPT][D], bv[PPT][D];
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) one(o.x[i], o.v[i], o.go[i], o.gt[i], bx[i], bv[i]);
-            store_chunk_nt<D>(grad_x, c, bx);
-            store_chunk_nt<D>(grad_v, c, bv);
-        },
-        [&](long n) {
-            float xp[D], vp[D], go[D], gt[D], bx[D], bv[D];
-            load_point<D>(x, n, xp);
-            load_point<D>(v, n, vp);
-            load_point<D>(g_jv, n, gt);
-            if (g_out != nullptr) {
-                load_point<D>(g_out, n, go);
-            } else {
-#pragma unroll
-                for (int j = 0; j < D; ++j) go[j] = 0.0f;
-            }
-            one(xp, vp, go, gt, bx, bv);
-            store_point<D>(grad_x, n, bx);
-            store_point<D>(grad_v, n, bv);
-        });
+            for (int j = 0; j < D; ++j) go[j] = 0.0f;
+        }
+        one(xp, vp, go, gt, bx, bv);
+        store_point<D>(grad_x, n, bx);
+        store_point<D>(grad_v, n, bv);
+    };
+    if constexpr (GO) {
+        const float* const arrs[4] = {x, v, g_jv, g_out};
+        for_each_chunk_ring<D, BLOCK, R, 4>(N, vec, arrs, chunk, point);
+    } else {
+        const float* const arrs[3] = {x, v, g_jv};
+        for_each_chunk_ring<D, BLOCK, R, 3>(N, vec, arrs, chunk, point);
+    }
     emit_partials<NACC>(acc, ws, fin);
 }
 
@@ -1440,6 +1506,7 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_kernel(const float* __restric
                                                           long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, int n_steps, float dt,
                                                           float* __restrict__ x_out, float* __restrict__ t_out) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, PPT = Chunk<D>::PPT;
     float w[D * Lib::P];
     load_xi<Lib>(xi, mask, 0, w);
@@ -1453,8 +1520,7 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_kernel(const float* __restric
             load_chunk<D>(v, c, o.t);
         },
         [&](long c, Ops& o) {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) euler_tangent_steps<Lib>(w, o.x[i], o.t[i], n_steps, dt);
+            each_point<PPT>([&](auto i) { euler_tangent_steps<Lib>(w, o.x[i], o.t[i], n_steps, dt); });
             store_chunk_nt<D>(x_out, c, o.x);
             store_chunk_nt<D>(t_out, c, o.t);
         },
@@ -1480,10 +1546,11 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __res
                                                               const float* __restrict__ mask, int n_steps, float dt,
                                                               float* __restrict__ grad_x, float* __restrict__ grad_v,
                                                               double* __restrict__ ws, Finish fin) {
+    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, NACC = 1 + D * P, PPT = Chunk<D>::PPT;
     extern __shared__ float stack[];
     float w[D * P];
-    load_xi<Lib>(xi, mask, 0, w);
+    load_xi<Lib, VGPR_XI_MAX + 1, 80>(xi, mask, 0, w);   // (th, dth, bar, dbar live per point: Xi leaves the vector file up to 80 coefficients)
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
@@ -1558,8 +1625,7 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __res
             load_chunk<D>(g_t, c, o.at);
         },
         [&](long c, Ops& o) {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) one(o.x[i], o.t[i], o.ax[i], o.at[i]);
+            each_point<PPT>([&](auto i) { one(o.x[i], o.t[i], o.ax[i], o.at[i]); });
             store_chunk_nt<D>(grad_x, c, o.ax);
             store_chunk_nt<D>(grad_v, c, o.at);
         },
@@ -1573,7 +1639,14 @@ __global__ __launch_bounds__(BLOCK) void euler_jvp_vjp_kernel(const float* __res
             store_point<D>(grad_x, n, ax);
             store_point<D>(grad_v, n, at);
         });
-    emit_partials<NACC>(acc, ws, fin);
+    if constexpr (STACK) {
+        // the state column is dead now: the reduction stages in it (the launcher sizes the region for both), which is
+        // what lets a K = 10 workgroup fit four to a CU (40 KB instead of 40 + 17)
+        __syncthreads();
+        emit_partials_in<NACC>(acc, ws, fin, stack);
+    } else {
+        emit_partials<NACC>(acc, ws, fin);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1834,7 +1907,10 @@ hipError_t launch_vjp(const float* x, const float* g, long n, const float* xi, c
     double* part = ws + WS_HEADER_DOUBLES;
     const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
     const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(g, n, Lib::D, 1) && (grad_x == nullptr || vec_ok(grad_x, n, Lib::D, 1));
-    vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, vec, xi, mask, grad_x, part, fin);
+    if (grad_x != nullptr)
+        vjp_kernel<Lib, true><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, vec, xi, mask, grad_x, part, fin);
+    else
+        vjp_kernel<Lib, false><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, g, n, vec, xi, mask, nullptr, part, fin);
     SYMODE_LAUNCH_CHECK();
     return launch_finalize(fin, part, 1, gx, NACC, st);
 }
@@ -1860,7 +1936,10 @@ hipError_t launch_jvp_vjp(const float* x, const float* v, const float* g_out, co
     const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
     const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(v, n, Lib::D, 1) && vec_ok(g_jv, n, Lib::D, 1) &&
                      (g_out == nullptr || vec_ok(g_out, n, Lib::D, 1)) && vec_ok(grad_x, n, Lib::D, 1) && vec_ok(grad_v, n, Lib::D, 1);
-    jvp_vjp_kernel<Lib><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, vec, xi, mask, grad_x, grad_v, part, fin);
+    if (g_out != nullptr)
+        jvp_vjp_kernel<Lib, true><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_out, g_jv, n, vec, xi, mask, grad_x, grad_v, part, fin);
+    else
+        jvp_vjp_kernel<Lib, false><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, nullptr, g_jv, n, vec, xi, mask, grad_x, grad_v, part, fin);
     SYMODE_LAUNCH_CHECK();
     return launch_finalize(fin, part, 1, gx, NACC, st);
 }
@@ -1885,13 +1964,14 @@ hipError_t launch_euler_jvp_vjp(const float* x, const float* v, const float* g_x
     const Finish fin = make_finish(ws, mask, 0.0f, 1.0f, nullptr, grad_xi);
     const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(v, n, Lib::D, 1) && vec_ok(g_x, n, Lib::D, 1) && vec_ok(g_t, n, Lib::D, 1) &&
                      vec_ok(grad_x, n, Lib::D, 1) && vec_ok(grad_v, n, Lib::D, 1);
-    // per-thread LDS column for the K states while it fits (40 KB at K = 10, D = 2, next to 17 KB of reduction staging:
-    // two workgroups per CU); SYMODE_EULER_STACK=0 forces the recompute form (A/B and the parity test)
+    // per-thread LDS column for the K states while it fits (40 KB at K = 10, D = 2: four workgroups per CU now that the
+    // reduction stages inside the column); SYMODE_EULER_STACK=0 forces the recompute form (A/B and the parity test)
     const size_t stack_bytes = (size_t)n_steps * 2 * Lib::D * BLOCK * sizeof(float);
+    const size_t stage_bytes = reduce_lds_floats(BLOCK) * sizeof(float);        // the reduction reuses the column afterwards
     const char* se = getenv("SYMODE_EULER_STACK");
     const bool use_stack = n_steps > 1 && stack_bytes <= 64 * 1024 && !(se && se[0] == '0');
     if (use_stack)
-        euler_jvp_vjp_kernel<Lib, true><<<dim3(gx, 1), dim3(BLOCK), stack_bytes, st>>>(x, v, g_x, g_t, n, vec, xi, mask, n_steps, dt,
+        euler_jvp_vjp_kernel<Lib, true><<<dim3(gx, 1), dim3(BLOCK), stack_bytes > stage_bytes ? stack_bytes : stage_bytes, st>>>(x, v, g_x, g_t, n, vec, xi, mask, n_steps, dt,
                                                                                       grad_x, grad_v, part, fin);
     else
         euler_jvp_vjp_kernel<Lib, false><<<dim3(gx, 1), dim3(BLOCK), 0, st>>>(x, v, g_x, g_t, n, vec, xi, mask, n_steps, dt, grad_x,

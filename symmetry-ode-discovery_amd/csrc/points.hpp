@@ -6,7 +6,30 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace symode {
+
+// The points of a chunk, one after the other: body(i) with i a COMPILE-TIME constant in each of the PPT copies of the body.
+// Template recursion, not `#pragma unroll`: the pragma is a request, and around bodies with inlined sinf / expf the
+// optimiser declines it beyond its size threshold ("loop not unrolled", -Wpass-failed) -- the loop variable then indexes
+// the per-chunk point arrays at run time and they land in scratch (100-600 bytes per lane in the D = 3 sine libraries).
+// (Tried and dropped for those libraries: ONE copy of the body in a real loop with the point arrays rotated by a row per
+//  pass -- no scratch, half the registers, but hipcc 7.2 emitted the loop-carried row copies as KILL pseudo-ops and every
+//  point of a chunk came out wrong; the same loop with row `pass` swapped in and out behind uniform branches was right
+//  and back in scratch.  Those libraries take the per-point path instead: kernels.hpp, chunked_stream.)
+template <int I, int N, typename F>
+__device__ __forceinline__ void each_point_static(F&& body) {
+    if constexpr (I < N) {
+        body(std::integral_constant<int, I>{});
+        each_point_static<I + 1, N>(body);
+    }
+}
+
+template <int PPT, typename F>
+__device__ __forceinline__ void each_point(F&& body) {
+    each_point_static<0, PPT>(body);
+}
 
 template <int D>
 struct Chunk {
@@ -42,21 +65,27 @@ __device__ __forceinline__ void exchange_tile3(const float4 (&t)[3], float4 (&v)
     for (int i = 0; i < 3; ++i) slab[64 * i + lane] = t[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // in front of the reads: behind them it sends v[] through scratch
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = slab[3 * lane + i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                     // the next exchange reuses the slab
+    __builtin_amdgcn_wave_barrier();                     // the next exchange reuses the slab (a wave's LDS operations run in order)
 }
 
-// Reverse direction for stores: v (this lane's chunk) -> t (tile order).
-__device__ __forceinline__ void exchange_tile3_out(const float4 (&v)[3], float4 (&t)[3], float4* slab, int lane) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) slab[3 * lane + i] = v[i];
+// Reverse direction for stores: v (this lane's chunk) -> t (tile order).  Plain vector VALUES in and out: with float4
+// arrays by reference the result array stayed a stack object and went through scratch around the wave barrier
+// (64 bytes per lane in every D = 3 kernel that stores points).
+typedef float f4x __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void exchange_tile3_out(f4x v0, f4x v1, f4x v2, f4x& t0, f4x& t1, f4x& t2, float4* slab, int lane) {
+    f4x* s = reinterpret_cast<f4x*>(slab);
+    s[3 * lane + 0] = v0;
+    s[3 * lane + 1] = v1;
+    s[3 * lane + 2] = v2;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = slab[64 * i + lane];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    t0 = s[lane];
+    t1 = s[64 + lane];
+    t2 = s[128 + lane];
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -144,13 +173,13 @@ __device__ __forceinline__ void store_chunk(float* __restrict__ a, long c, const
         if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {           // whole wave: coalesced tile stores (see load_chunk)
             SYMODE_TILE3_SLAB(slab);
             const int lane = threadIdx.x & 63;
-            float4 v[3], t[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) v[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
-            exchange_tile3_out(v, t, slab[threadIdx.x >> 6], lane);
-            float4* tile = reinterpret_cast<float4*>(a) + (c - lane) * 3 + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) tile[64 * i] = t[i];
+            f4x t0, t1, t2;
+            exchange_tile3_out(f4x{f[0], f[1], f[2], f[3]}, f4x{f[4], f[5], f[6], f[7]}, f4x{f[8], f[9], f[10], f[11]}, t0, t1, t2,
+                               slab[threadIdx.x >> 6], lane);
+            f4x* tile = reinterpret_cast<f4x*>(a) + (c - lane) * 3 + lane;
+            tile[0] = t0;
+            tile[64] = t1;
+            tile[128] = t2;
             return;
         }
     }
@@ -243,6 +272,34 @@ __device__ __forceinline__ void for_each_chunk2(long N, bool vec, Load load, Com
     }
 }
 
+// The ring itself, for callers whose chunk is more than NA equal arrays (the regulariser's J_g): `slot` = NVTOT 16-byte
+// registers per chunk, load(q, slot) issues chunk q's loads into them (q already clamped to the last chunk),
+// use(c, slot) consumes chunk c.  Chunks c0, c0 + stride, ... < nchunks, in that order.
+template <int R, int NVTOT, typename Load, typename Use>
+__device__ __forceinline__ void chunk_ring(long nchunks, long c0, long stride, Load load, Use use) {
+    if (nchunks <= 0) return;
+    const long lastc = nchunks - 1;
+    float4 ring[R][NVTOT];
+    long c = c0;
+    // (slot loops by template recursion: `#pragma unroll` is declined around large bodies, and a ring indexed at run time
+    //  is a ring in scratch)
+    each_point_static<0, R>([&](auto k) {
+        const long cc = c + k * stride;
+        load(cc < lastc ? cc : lastc, ring[k]);
+    });
+    for (; c + (R - 1) * stride < nchunks; c += R * stride) {
+        each_point_static<0, R>([&](auto k) {
+            use(c + k * stride, ring[k]);
+            const long cc = c + (R + k) * stride;
+            load(cc < lastc ? cc : lastc, ring[k]);
+            __builtin_amdgcn_sched_barrier(0);           // keep the refill here: the scheduler would sink all R to the loop end
+        });
+    }
+    each_point_static<0, R>([&](auto k) {
+        if (c + k * stride < nchunks) use(c + k * stride, ring[k]);
+    });
+}
+
 // Register-ring pipeline over NA operand arrays of one (N, D) problem: every lane keeps R chunks of every operand in
 // flight -- the slot a chunk has just been consumed from is refilled at once with the chunk R rounds ahead (16-byte
 // non-temporal loads; indices past the end are clamped to the last chunk, so the tail over-reads in bounds and the
@@ -279,34 +336,29 @@ __device__ __forceinline__ void for_each_chunk_ring(long N, bool vec, const floa
             for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c, a[q]);
             compute(c, a);
         }
-    } else if (nchunks > 0) {
-        const long lastc = nchunks - 1;
-        float4 ring[R][NA][NV];
-        auto ld = [&](long cc, float4 (&slot)[NA][NV]) {
-            const long q = cc < lastc ? cc : lastc;
+    } else {
+        chunk_ring<R, NA * NV>(
+            nchunks, tid, nthreads,
+            [&](long q, float4 (&slot)[NA * NV]) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) load_chunk_raw<D, true>(arr[a], q, slot[a]);
-        };
-        auto use = [&](long cc, const float4 (&slot)[NA][NV]) {
-            float pts[NA][PPT][D];
+                for (int a = 0; a < NA; ++a) {
+                    float4 v[NV];
+                    load_chunk_raw<D, true>(arr[a], q, v);
 #pragma unroll
-            for (int a = 0; a < NA; ++a) unpack_chunk<D>(slot[a], pts[a]);
-            compute(cc, pts);
-        };
-        long c = tid;
+                    for (int i = 0; i < NV; ++i) slot[a * NV + i] = v[i];
+                }
+            },
+            [&](long cc, const float4 (&slot)[NA * NV]) {
+                float pts[NA][PPT][D];
 #pragma unroll
-        for (int k = 0; k < R; ++k) ld(c + k * nthreads, ring[k]);
-        for (; c + (R - 1) * nthreads < nchunks; c += R * nthreads) {
+                for (int a = 0; a < NA; ++a) {
+                    float4 v[NV];
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                use(c + k * nthreads, ring[k]);
-                ld(c + (R + k) * nthreads, ring[k]);
-                __builtin_amdgcn_sched_barrier(0);       // keep the refill here: the scheduler would sink all R to the loop end
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-            if (c + k * nthreads < nchunks) use(c + k * nthreads, ring[k]);
+                    for (int i = 0; i < NV; ++i) v[i] = slot[a * NV + i];
+                    unpack_chunk<D>(v, pts[a]);
+                }
+                compute(cc, pts);
+            });
     }
     const long n = nchunks * PPT + tid;
     if (n < N) point_body(n);

@@ -174,3 +174,22 @@ def test_header_is_plain_c_and_the_c_example_compiles():
                             "-lsymode_hip", f"-L{rocm}/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}/lib",
                             "-o", out], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_no_scratch_inside_the_reference_domain():
+    """No kernel of a library the reference can build (any latent_dim here <= 3, order <= 3, sine / exp on or off --
+    sindy.py:42-77) nor any d <= 2 kernel of the order 4-5 extension touches scratch memory: the gfx950 code objects are
+    pulled out of the built library and disassembled (tools/scratch_report.py)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (os.path.exists(engine.LIB_PATH) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        pytest.skip("needs the built library and llvm-objdump")
+    spec = importlib.util.spec_from_file_location("scratch_report", os.path.join(root, "tools", "scratch_report.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.scratch_by_kernel(engine.LIB_PATH)
+    assert len(res) > 500                                            # the extraction found the kernels
+    import re
+    inside = re.compile(r"Library<(?:[123], [123]|[12], [45]), ")
+    bad = {k: v for k, v in res.items() if v > 0 and inside.search(k)}
+    assert not bad, bad
