@@ -39,6 +39,10 @@ extern "C" {
 
 /* ABI version of this header (bumped on any signature change). */
 int symode_abi_version(void);
+
+/* The optional SYMODE_* tuning / A-B variables are read once, when the library is first used; this
+ * reads them again (tests and tuning tools that compare two settings inside one process).  No reference counterpart. */
+void symode_reload_env(void);
 const char* symode_error_string(int code);
 
 /* p = number of library columns; SYMODE_E_UNSUPPORTED if (d, order, flags) is not compiled in.

@@ -76,7 +76,11 @@ class BatchedClosure:
         self.group = group
         self.distributed = group is not None or (world_size or 1) > 1
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if self.distributed else 1)
-        self.n_global = self.n_local * self.world            # equal shards (weak scaling)
+        self.n_global = self.n_local * self.world
+        if group is not None:                                # shards need not be equal: the count is summed once, at set-up
+            cnt = torch.tensor([float(self.n_local)], dtype=torch.float64, device=x.device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+            self.n_global = int(cnt.item())
         self.inv_count = 1.0 / (self.n_global * self.d)
         self.n_chunks = max(1, min(n_chunks, self.S))
         nacc = 1 + self.d * self.p

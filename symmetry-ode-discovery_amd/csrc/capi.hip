@@ -31,16 +31,12 @@ inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p % a) != 0
 // one wave per SIMD cannot cover the LDS round trip between MFMAs; SYMODE_GRAM_GRID for tuning runs) keeps the
 // number of partials the single finalize block has to add small.
 inline int gram_grid(long n, long S) {
-    static const long total = [] {
-        const char* e = getenv("SYMODE_GRAM_GRID");
-        const long v = e ? atol(e) : 1024;
-        return v < 2 ? 2 : v;
-    }();
+    const long total = knobs().gram_grid < 0 ? 1024 : (knobs().gram_grid < 2 ? 2 : knobs().gram_grid);
     const long g = grid_x_by_points(n, 1);
     long cap = S >= total / 2 ? 2 : total / S;
     // one problem: the single finalize block adds every partial (6 KB each at two tiles): 125 000 points cost 84 us on
     // 1024 workgroups, 34 us on 128; 1 M points 178 vs 83 us on 256; 16 M 596 vs 564 us on 512 (r02_single_grid.txt)
-    if (S == 1 && !getenv("SYMODE_GRAM_GRID")) cap = n <= 300000 ? 128 : n <= 2000000 ? 256 : n <= 32000000 ? 512 : total;
+    if (S == 1 && knobs().gram_grid < 0) cap = n <= 300000 ? 128 : n <= 2000000 ? 256 : n <= 32000000 ? 512 : total;
     return (int)(g > cap ? cap : g);
 }
 
@@ -52,8 +48,7 @@ inline int gram_grid(long n, long S) {
 //                                          16 M        308 /  170 /  113 /  118    64 M 1195 /  645 /  432 /  447
 // SYMODE_SMALL_GRID fixes the cap for tuning runs (0 = none).
 inline int small_grid_cap(long n, bool with_regulariser) {
-    const char* e = getenv("SYMODE_SMALL_GRID");
-    if (e) return atoi(e);
+    if (knobs().small_grid >= 0) return (int)knobs().small_grid;
     if (with_regulariser) return n <= 300000 ? 128 : (n <= 1500000 ? 256 : 512);
     return n <= 1500000 ? 128 : 256;
 }
@@ -61,16 +56,12 @@ inline int small_grid_cap(long n, bool with_regulariser) {
 // The vector-pipe Gram (gram_valu.hpp) holds two workgroups per CU (register-bound): one balanced round of them for a
 // single large problem, the streaming grid for batches; its partial rows are 78 doubles, so many workgroups are cheap.
 inline int gram_valu_grid(long n, long S, int d) {
-    static const long total = [] {
-        const char* e = getenv("SYMODE_GRAM_VALU_GRID");
-        const long v = e ? atol(e) : 1024;
-        return v < 2 ? 2 : v;
-    }();
+    const long total = knobs().gram_valu_grid < 0 ? 1024 : (knobs().gram_valu_grid < 2 ? 2 : knobs().gram_valu_grid);
     // at least 32 points per thread: the epilogue transposes 78 fp64 sums per thread through LDS (ten rounds), which a
     // thread must amortise over its own 78-fma-per-point work; beyond that, enough workgroups to fill the chip
     long g = (n + 256L * 32 - 1) / (256L * 32);
     long want = (total + S - 1) / S;                       // ~`total` workgroups in all
-    if (S == 1 && want > 512 && !getenv("SYMODE_GRAM_VALU_GRID")) want = 512;   // one problem: 16 M points 84 vs 97 us, 64 M equal
+    if (S == 1 && want > 512 && knobs().gram_valu_grid < 0) want = 512;   // one problem: 16 M points 84 vs 97 us, 64 M equal
     if (g > want) g = want;
     if (g < 1) g = 1;
     return (int)g;
@@ -88,7 +79,7 @@ inline int gram_valu_grid(long n, long S, int d) {
 //  profiles/r03_stream_ab.txt, 64 .. 1024 workgroups at 125 000 .. 64 M points)
 // hence a cap per size class: <= 300 K points, <= 2 M, <= 16 M, beyond.  SYMODE_REDUCE_GRID overrides it for tuning runs.
 inline int single_problem_grid(int gx, long n, int c_small, int c_mid, int c_large, int c_huge) {
-    static const int env = getenv("SYMODE_REDUCE_GRID") ? atoi(getenv("SYMODE_REDUCE_GRID")) : 0;
+    const int env = (int)knobs().reduce_grid;
     const int c = env > 0 ? env : (n <= 300000 ? c_small : n <= 2000000 ? c_mid : n <= 16000000 ? c_large : c_huge);
     return gx > c ? c : gx;
 }
@@ -114,7 +105,9 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
 
 extern "C" {
 
-int symode_abi_version(void) { return 3; }
+int symode_abi_version(void) { return 4; }
+
+void symode_reload_env(void) { knobs() = read_knobs(); }
 
 const char* symode_error_string(int code) {
     switch (code) {

@@ -317,23 +317,14 @@ __global__ __launch_bounds__(BLOCK) void gram_split_finalize_kernel(const double
     }
 }
 
-inline bool gram_split_enabled() {
-    const char* e = getenv("SYMODE_GRAM_SPLIT");      // A-B knob: 0 keeps the MFMA form for 12 < F <= 24
-    return !(e && e[0] == '0');
-}
+inline bool gram_split_enabled() { return knobs().gram_split != 0; }      // A-B knob: 0 keeps the MFMA form for 12 < F <= 24
 
 // Index-table launches (seed sweeps over sorted subsamples): the vector-pipe form prefetches the next point's rows and,
 // since the launch geometry gives every thread >= 32 points, beats the MFMA form here too (r02_gather_gram.txt: 64 x 500 000
 // of 1 M rows 259 vs 410 us; 256 x 200 000 of 2 M rows 423 vs 634 us).  SYMODE_GRAM_VALU_GATHER=0 keeps the MFMA form.
-inline bool gram_valu_gather_enabled() {
-    const char* e = getenv("SYMODE_GRAM_VALU_GATHER");
-    return !(e && e[0] == '0');
-}
+inline bool gram_valu_gather_enabled() { return knobs().gram_valu_gather != 0; }
 
-inline bool gram_valu_enabled() {
-    const char* e = getenv("SYMODE_GRAM_VALU");       // tuning / A-B knob: 0 forces the MFMA form for every library
-    return !(e && e[0] == '0');
-}
+inline bool gram_valu_enabled() { return knobs().gram_valu != 0; }       // tuning / A-B knob: 0 forces the MFMA form for every library
 
 template <class Lib>
 hipError_t launch_aug_gram_any(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
@@ -357,7 +348,7 @@ hipError_t launch_aug_gram_any(const float* x, const float* dx, long S, long n, 
             // one problem: 128 columns x NPART runs = one resident round of the chip (2 workgroups per CU at 193 VGPRs):
             // 16 M points, order 5: 268 us against 334 us on 1024 columns (r02_gram_split.txt)
             int GX = (gx_valu + 7) / 8 * 8;
-            if (S == 1 && GX > 128 && !getenv("SYMODE_GRAM_VALU_GRID")) GX = 128;
+            if (S == 1 && GX > 128 && knobs().gram_valu_grid < 0) GX = 128;
             aug_gram_split_kernel<Lib><<<dim3(GX * GramSplitShape<Lib>::NPART, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, n, vec, GX, part);
             SYMODE_LAUNCH_CHECK();
             gram_split_finalize_kernel<Lib><<<dim3((unsigned)S), dim3(BLOCK), 0, st>>>(part, GX, gram);

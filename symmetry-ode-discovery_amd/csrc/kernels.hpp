@@ -16,6 +16,41 @@ constexpr int BLOCK = 256;
 #define SYMODE_MAP_CHUNKS 1
 #endif
 constexpr int MAP_CHUNKS_PER_THREAD = SYMODE_MAP_CHUNKS;   // chunks a thread of a map kernel visits (grid = index space / this)
+
+// Every SYMODE_* tuning / A-B variable the library knows, read ONCE when the library is first used.
+// A value of -1 means "not set: the library's own rule".  symode_reload_env() (C ABI) reads the environment again --
+// for the tests and tuning tools that compare two settings inside one process; no launch path calls getenv.
+struct Knobs {
+    long max_grid, min_grid_x, map_grid, gram_grid, gram_valu_grid, small_grid, reduce_grid;
+    int fused_finalize, euler_stack, gram_valu, gram_split, gram_valu_gather, loss_grad_variant, segmented, row_split;
+};
+
+inline Knobs read_knobs() {
+    auto num = [](const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; };
+    auto on = [](const char* name) { const char* e = getenv(name); return (e && e[0] == '0') ? 0 : 1; };
+    Knobs k;
+    k.max_grid = num("SYMODE_MAX_GRID", -1);
+    k.min_grid_x = num("SYMODE_MIN_GRID_X", 2);
+    k.map_grid = num("SYMODE_MAP_GRID", 1L << 20);
+    k.gram_grid = num("SYMODE_GRAM_GRID", -1);
+    k.gram_valu_grid = num("SYMODE_GRAM_VALU_GRID", -1);
+    k.small_grid = num("SYMODE_SMALL_GRID", -1);
+    k.reduce_grid = num("SYMODE_REDUCE_GRID", -1);
+    k.fused_finalize = (int)num("SYMODE_FUSED_FINALIZE", 1);
+    k.euler_stack = on("SYMODE_EULER_STACK");
+    k.gram_valu = on("SYMODE_GRAM_VALU");
+    k.gram_split = on("SYMODE_GRAM_SPLIT");
+    k.gram_valu_gather = on("SYMODE_GRAM_VALU_GATHER");
+    k.loss_grad_variant = (int)num("SYMODE_LOSS_GRAD_VARIANT", -1);
+    k.segmented = (int)num("SYMODE_SEGMENTED", 1);
+    k.row_split = (int)num("SYMODE_ROW_SPLIT", 1);
+    return k;
+}
+
+inline Knobs& knobs() {
+    static Knobs k = read_knobs();
+    return k;
+}
 // Workgroup budget of a BATCHED reduction launch (S > 1 problems on grid.y).  Every workgroup pays a fixed epilogue (LDS
 // transpose of its d*p + 1 sums, a partial row, a ticket) and the last one of each problem adds that problem's rows
 // alone, so what a launch wants is few, long-lived workgroups: ~16 K points each, between one per CU and four per CU in
@@ -26,7 +61,7 @@ constexpr int MAP_CHUNKS_PER_THREAD = SYMODE_MAP_CHUNKS;   // chunks a thread of
 // The fused closure (40 B/point, 3-4 waves per SIMD) wants twice the floor: 16 x 125 000: 26.6 us at 256, 22.4 at 512, 37.0
 // at 2048; 64 x 50 000: 38.0 / 27.3 / 36.5 (profiles/r02_batched_grid.txt).
 inline long batch_grid_budget(long total_points, long floor_) {
-    static const long fixed = getenv("SYMODE_MAX_GRID") ? atol(getenv("SYMODE_MAX_GRID")) : 0;
+    const long fixed = knobs().max_grid;
     if (fixed > 0) return fixed < 2 ? 2 : fixed;
     long b = total_points / 16384;
     if (b < floor_) b = floor_;
@@ -35,7 +70,7 @@ inline long batch_grid_budget(long total_points, long floor_) {
 }
 
 inline long min_grid_x() {
-    static const long v = getenv("SYMODE_MIN_GRID_X") ? atol(getenv("SYMODE_MIN_GRID_X")) : 2;
+    const long v = knobs().min_grid_x;
     return v < 1 ? 1 : v;
 }
 
@@ -110,7 +145,7 @@ inline int grid_x_for(long n, long S, int pts_per_thread_iter, long batch_floor 
 // forward map at 2^26 points: 0.77 of the HBM roof, against 0.58-0.71 for 1024-8192 looping workgroups).
 // SYMODE_MAP_GRID caps it for tuning runs.
 inline int map_grid_for(long n, int pts_per_thread_iter) {
-    static const long cap = getenv("SYMODE_MAP_GRID") ? atol(getenv("SYMODE_MAP_GRID")) : (1L << 20);
+    const long cap = knobs().map_grid;
     const long per_block = (long)BLOCK * pts_per_thread_iter * MAP_CHUNKS_PER_THREAD;
     long g = (n + per_block - 1) / per_block;
     if (g > cap) g = cap;
@@ -440,20 +475,46 @@ __device__ __forceinline__ void emit_partials_in(float (&acc)[NACC], double* __r
         }
         return;
     }
+    unsigned* ticket = ws_tickets(fin.header) + s;
+    double* comb = reinterpret_cast<double*>(lds);       // BLOCK doubles fit in the staging area
+    static_assert(sizeof(float) * reduce_lds_floats(BLOCK) >= sizeof(double) * BLOCK, "LDS too small for the combine");
+    if (fin.fused == 2) {
+        // SYMODE_FUSED_FINALIZE=2: the hand-off in the memory model's own terms (MI355X_MICROARCH.md, Valid forms, first
+        // bullet) -- plain stores, every wave drained, barrier, ONE agent-scope release by the signalling lane before its
+        // ticket add; the last block makes ONE agent-scope acquire before anybody reads the rows with plain loads.
+        // ~3 us per launch dearer than the sc1 form below (a write-back and an invalidate on the critical path of the last
+        // block), which is why it is not the default; same sums in the same order, so the same bits (tested).
+        block_reduce_emit_lds<NACC, BLOCK>(acc, lds, [&](int k, double v) { dst[k] = v; });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = (t == (unsigned)(G - 1)) ? 1u : 0u;
+            if (last_flag != 0u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (last_flag == 0u) return;
+        combine_rows<false>(part + s * (long)G * NACC, G, NACC, fin.n_loss, s, fin.mask, fin.loss_scale, fin.grad_scale, fin.loss,
+                            fin.grad, comb);
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     block_reduce_emit_lds<NACC, BLOCK>(acc, lds, [&](int k, double v) {
         __hip_atomic_store(dst + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave has its row out before the ticket
     __syncthreads();
-    unsigned* ticket = ws_tickets(fin.header) + s;
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (t == (unsigned)(G - 1)) ? 1u : 0u;
     }
     __syncthreads();
     if (last_flag == 0u) return;
-    double* comb = reinterpret_cast<double*>(lds);       // BLOCK doubles fit in the staging area
-    static_assert(sizeof(float) * reduce_lds_floats(BLOCK) >= sizeof(double) * BLOCK, "LDS too small for the combine");
     combine_rows<true>(part + s * (long)G * NACC, G, NACC, fin.n_loss, s, fin.mask, fin.loss_scale, fin.grad_scale, fin.loss,
                        fin.grad, comb);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
@@ -477,10 +538,7 @@ __global__ __launch_bounds__(BLOCK) void workspace_init_kernel(unsigned long lon
     if (i < n_words) header[i] = (i == 0) ? WS_MAGIC : 0ull;
 }
 
-inline bool fused_finalize_enabled() {
-    const char* e = getenv("SYMODE_FUSED_FINALIZE");      // read per call: tests flip it inside one process
-    return !(e && e[0] == '0');
-}
+inline int fused_finalize_mode() { return (int)knobs().fused_finalize; }      // 0 two launches, 1 sc1 hand-off (default), 2 fenced hand-off
 
 // ---------------------------------------------------------------------------------------
 // K1: fused Theta + residual + MSE + gradient                  (closure body + backward)
@@ -1698,13 +1756,7 @@ hipError_t launch_odeint(const float* x, long n, const float* xi, const float* m
     return hipSuccess;
 }
 
-inline int loss_grad_variant() {
-    static const int v = [] {
-        const char* e = getenv("SYMODE_LOSS_GRAD_VARIANT");
-        return e ? atoi(e) : -1;          // -1: the library's own default
-    }();
-    return v;
-}
+inline int loss_grad_variant() { return knobs().loss_grad_variant; }          // -1: the library's own default
 
 // ---------------------------------------------------------------------------------------
 // K1 for large libraries (D * P > SGPR_XI_MAX: d = 3 order 4, d = 4 order 3, sine/exp variants): one ROW per wave.
@@ -1793,7 +1845,7 @@ __global__ __launch_bounds__(Lib::D* WAVE) void loss_grad_rows_kernel(const floa
 // `ws` of every launcher below is the caller's workspace base: [header | partials].
 inline Finish make_finish(double* ws, const float* mask, float loss_scale, float grad_scale, float* loss, float* grad) {
     return Finish{reinterpret_cast<unsigned long long*>(ws), mask, loss_scale, grad_scale, loss, grad,
-                  fused_finalize_enabled() ? 1 : 0, 1};
+                  fused_finalize_mode(), 1};
 }
 
 // second launch of the two-launch path
@@ -1818,7 +1870,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
         return nb * cu;
     }();
     if (S == 1 && gx > resident) gx = resident;
-    static const int seg_env = getenv("SYMODE_SEGMENTED") ? atoi(getenv("SYMODE_SEGMENTED")) : 1;
+    const int seg_env = knobs().segmented;
     // contiguous slab per workgroup: 1 = for one big problem, 2 = also inside every problem of a batch
     const bool seg = (seg_env == 1 && S == 1 && gx >= 64) || (seg_env == 2 && gx >= 2);
     const dim3 grid(gx, (unsigned)S), block(BLOCK);
@@ -1827,7 +1879,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // row-per-wave kernel; the experimental variants are not even instantiated for them.
     constexpr bool TUNED = (Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX);
     constexpr bool ROWS = (Lib::D >= 2) && (Lib::D * Lib::P > SGPR_XI_MAX);
-    static const int rows_env = getenv("SYMODE_ROW_SPLIT") ? atoi(getenv("SYMODE_ROW_SPLIT")) : 1;
+    const int rows_env = knobs().row_split;
     double* part = ws + WS_HEADER_DOUBLES;
     Finish fin = make_finish(ws, mask, inv_count, 2.0f * inv_count, loss, grad);
     if constexpr (ROWS) {
@@ -1968,8 +2020,7 @@ hipError_t launch_euler_jvp_vjp(const float* x, const float* v, const float* g_x
     // reduction stages inside the column); SYMODE_EULER_STACK=0 forces the recompute form (A/B and the parity test)
     const size_t stack_bytes = (size_t)n_steps * 2 * Lib::D * BLOCK * sizeof(float);
     const size_t stage_bytes = reduce_lds_floats(BLOCK) * sizeof(float);        // the reduction reuses the column afterwards
-    const char* se = getenv("SYMODE_EULER_STACK");
-    const bool use_stack = n_steps > 1 && stack_bytes <= 64 * 1024 && !(se && se[0] == '0');
+    const bool use_stack = n_steps > 1 && stack_bytes <= 64 * 1024 && knobs().euler_stack != 0;
     if (use_stack)
         euler_jvp_vjp_kernel<Lib, true><<<dim3(gx, 1), dim3(BLOCK), stack_bytes > stage_bytes ? stack_bytes : stage_bytes, st>>>(x, v, g_x, g_t, n, vec, xi, mask, n_steps, dt,
                                                                                       grad_x, grad_v, part, fin);

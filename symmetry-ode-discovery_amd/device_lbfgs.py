@@ -96,6 +96,10 @@ class DeviceTrainer:
         self.log_mask = mk(R, self.S, self.dp) if self.detail else None
         self.log_params = mk(R, self.S, self.n) if self.detail else None
         n_global = self.n_points * world
+        if group is not None and inv_count is None:          # shards need not be equal: the count is summed once, at set-up
+            cnt = torch.tensor([float(self.n_points)], dtype=torch.float64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+            n_global = int(cnt.item())
         T = TrainerDesc()
         T.x, T.dx = self.x.data_ptr(), self.dx.data_ptr()
         if self.sym is not None:

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("SYMODE_LIB") or os.path.join(_HERE, "libsymode_hip.so
 # name -> (restype, argtypes); kept in step with include/symode.h (tests check every symbol)
 _SIGNATURES = {
     "symode_abi_version": (c_int, []),
+    "symode_reload_env": (None, []),
     "symode_error_string": (c_char_p, [c_int]),
     "symode_lib_size": (c_int, [c_int, c_int, c_int]),
     "symode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_long, c_long]),
@@ -78,7 +79,7 @@ _SIGNATURES = {
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TrainerDesc(ctypes.Structure):
@@ -118,6 +119,12 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     return lib
 
 
+def reload_env() -> None:
+    """Have the loaded library read its optional SYMODE_* variables again (it reads them once, at first use)."""
+    if _ENGINE is not None:
+        _ENGINE.lib.symode_reload_env()
+
+
 def library_flags(include_sine: bool, include_exp: bool) -> int:
     return (FLAG_SINE if include_sine else 0) | (FLAG_EXP if include_exp else 0)
 
@@ -131,6 +138,9 @@ class HipEngine:
 
     # -- plumbing ----------------------------------------------------------------------
     def _check(self, code: int, what: str):
+        if code > 0:
+            # a HIP error from a launch: whatever state the scratch buffers' tickets are in, the next call gets fresh ones
+            self._ws.clear()
         if code != 0:
             raise SymodeError(f"{what} failed: {self.lib.symode_error_string(code).decode()} (code {code})")
 

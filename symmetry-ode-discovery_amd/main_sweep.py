@@ -95,8 +95,7 @@ def main(argv=None, engine=None, backend='nccl', one_gpu=False):
     x_all, dx_all = train_dataset.x.to(dev), train_dataset.dx.to(dev)
     n_all = x_all.shape[0]
     m = int(n_all * args['lbfgs_subsample'])
-    m -= m % world                                       # equal shards: every rank normalises by the same global count
-    lo, hi = rank * m // world, (rank + 1) * m // world
+    lo, hi = rank * m // world, (rank + 1) * m // world  # shards may differ by a row: counts are summed over the ranks
     seeds = list(range(args['seed'], args['seed'] + n_seeds))
     gens = [torch.Generator().manual_seed(s) for s in seeds]
 

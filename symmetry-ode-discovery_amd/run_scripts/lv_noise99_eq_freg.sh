@@ -1,7 +1,7 @@
 #!/bin/bash
 # Seeds 0-49 of lv/noise99_eq_fsymreg.cfg, one process per seed like the reference's script of the same name.
 # Run from a directory that holds run_configs/ (this package directory does) with the repository root on
-# PYTHONPATH.  The whole loop as ONE process per GPU: python -m symode_amd.main_sweep --config lv/noise99_eq_fsymreg.cfg --n_seeds 50
+# PYTHONPATH.
 for i in {0..49}; do
     echo "Running seed $i"
     python -m symode_amd.main --seed "$i" --config lv/noise99_eq_fsymreg.cfg

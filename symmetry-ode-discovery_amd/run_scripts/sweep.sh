@@ -1,16 +1,23 @@
 #!/bin/bash
 # Seeds 0-49 of one equation-discovery config (the reference's run_scripts/*.sh loop over `python main.py --seed $i`).
-#   L-BFGS SINDy / EquivSINDy-c configs run all seeds in ONE process on the batched kernels;
-#   configs with an autoencoder / symmetry regulariser fall back to the per-seed loop.
+#   L-BFGS SINDy / EquivSINDy-c configs (no autoencoder, no latent model, no symmetry regulariser) run all seeds in ONE
+#   process on the batched kernels (main_sweep); weak-SINDy configs loop over main_wsindy, everything else over main.
 # usage (from symmetry-ode-discovery_amd/):  bash run_scripts/sweep.sh dosc/noise20_sindy.cfg
 set -e
 cfg=$1
 export PYTHONPATH=${PYTHONPATH:-..}
-if grep -q -- "--load_laligan\|--w_sym_reg 0\.[1-9]\|--use_latent" "run_configs/$cfg"; then
+file="run_configs/$cfg"
+per_seed() {
     for i in $(seq 0 49); do
         echo "Running seed $i"
-        python -m symode_amd.main --seed "$i" --config "$cfg"
+        python -m "symode_amd.$1" --seed "$i" --config "$cfg"
     done
-else
+}
+case "$cfg" in
+    *wsindy*) per_seed main_wsindy; exit 0 ;;
+esac
+if grep -q -- "--sindy_optimizer lbfgs" "$file" && ! grep -q -- "--load_laligan\|--use_latent\|--w_sym_reg 0\.0*[1-9]\|--w_sym_reg [1-9]" "$file"; then
     python -m symode_amd.main_sweep --seed 0 --n_seeds 50 --config "$cfg"
+else
+    per_seed main
 fi

@@ -311,3 +311,37 @@ def test_lbfgs_trainer_on_point_shards_with_relative_regulariser(tmp_path):
         assert np.array_equal(a["Xi"], b["Xi"]) and np.array_equal(a["mask"], b["mask"])
         assert np.array_equal(a["mask"], one["mask"])
         assert np.abs(a["Xi"] - one["Xi"]).max() <= 1e-3 * np.abs(one["Xi"]).max()
+
+
+def _odd_sweep_worker(rank, world, port, out_dir, method):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.chdir(out_dir)
+    torch.set_num_threads(1)
+    import symode_amd  # noqa: F401
+    from symode_amd import dataset as D, main_sweep
+    from tests.oracle_engine import OracleEngine
+    D._RECIPES["dosc"] = (6, 2, 600, 3, 0.01)                       # 1200 samples; 41.75 % of them = 501 rows per seed
+    argv = ["--task", "dosc", "--noise", "0.0", "--ae_arch", "none", "--sindy_optimizer", "lbfgs", "--lbfgs_subsample", "0.4175",
+            "--lr_sindy", "0.1", "--w_sindy_x", "1.0", "--w_sindy_z", "0.0", "--w_sindy_reg", "0.0", "--w_sym_reg", "0.0",
+            "--poly_order", "2", "--st_freq", "50", "--threshold", "5e-2", "--num_epochs", "60", "--save_dir", f"odd-{method}-{world}",
+            "--n_seeds", "3", "--method", method, "--seed", "0"]
+    main_sweep.main(argv, engine=OracleEngine(), backend="gloo")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_main_sweep_with_an_odd_subsample_fits_the_same_problems_on_one_two_and_three_ranks(tmp_path):
+    """501 rows per seed do not divide by 2 or 3: the shards differ by a row, the global count is summed over the ranks, and
+    every world size fits exactly the 1-rank problems -- same masks, coefficients to summation order (the old
+    `m -= m % world` dropped rows instead)."""
+    res = {}
+    for method in ("stlsq", "lbfgs"):
+        for world in (1, 2, 3):
+            mp.spawn(_odd_sweep_worker, args=(world, _free_port(), str(tmp_path), method), nprocs=world, join=True)
+            files = sorted((tmp_path / "eval_results" / f"odd-{method}-{world}").iterdir())
+            res[method, world] = np.stack([np.load(f)["coefficients"] for f in files])
+        for world in (2, 3):
+            assert np.array_equal(res[method, world] != 0, res[method, 1] != 0), (method, world)
+            tol = 1e-5 if method == "stlsq" else 1e-3            # L-BFGS: the optimiser's own stopping ball (see test_gpu_multirank)
+            assert np.abs(res[method, world] - res[method, 1]).max() <= tol * np.abs(res[method, 1]).max(), (method, world)

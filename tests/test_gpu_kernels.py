@@ -394,6 +394,7 @@ class _env:
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.kv}
         os.environ.update({k: str(v) for k, v in self.kv.items()})
+        _reload_env()                                  # the library reads its SYMODE_* variables once; re-read on request
 
     def __exit__(self, *exc):
         for k, v in self.old.items():
@@ -401,13 +402,21 @@ class _env:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _reload_env()
+
+
+def _reload_env():
+    import symode_amd
+    symode_amd.engine.reload_env()
 
 
 @pytest.mark.parametrize("S,n,d,order", [(1, 125000, 2, 5), (1, 999, 2, 3), (7, 4097, 2, 3), (1, 50000, 3, 2), (64, 20000, 2, 2),
                                          (1, 1 << 22, 2, 3)])
 def test_fused_finalize_bit_identical_to_two_launches(eng, S, n, d, order):
     """The last-workgroup-done epilogue adds the partial rows in the order finalize_kernel does: same bits;
-    repeated launches on the same workspace keep giving them (the tickets reset themselves)."""
+    repeated launches on the same workspace keep giving them (the tickets reset themselves).  Both in-launch hand-offs:
+    the default (write-through sc1 rows, no fence) and SYMODE_FUSED_FINALIZE=2 (plain rows behind an agent-scope release,
+    read behind an agent-scope acquire)."""
     torch.manual_seed(S + n)
     x = (torch.randn(S, n, d) * 0.7).cuda()
     dx = torch.randn(S, n, d).cuda()
@@ -420,6 +429,10 @@ def test_fused_finalize_bit_identical_to_two_launches(eng, S, n, d, order):
         for _ in range(3):
             l1, g1 = eng.loss_grad(x, dx, xi, mask, order)
             assert torch.equal(l0, l1) and torch.equal(g0, g1)
+    with _env(SYMODE_FUSED_FINALIZE=2):                 # the fenced hand-off (agent-scope release / acquire): same bits again
+        for _ in range(3):
+            l2, g2 = eng.loss_grad(x, dx, xi, mask, order)
+            assert torch.equal(l0, l2) and torch.equal(g0, g2)
     # fp64 sums of the oracle's fp32 library: at 4 M random points the oracle's own fp32 matmul is off by 4e-4
     th = O.theta(x[0].cpu(), order).double()
     w = (xi[0] * mask[0]).cpu().double()

@@ -29,6 +29,7 @@ def timeit(fn, reps, rounds=5):
 
 STREAM_OPS = ("symreg_linear", "symreg_reversed", "vjp", "vjp_noxgrad", "forward_jvp", "jvp_vjp", "euler_jvp", "euler_jvp_vjp",
               "odeint", "odeint_rk4", "gram_gather")
+EXTRA_OPS = ("weak_gram",)          # not part of --table: one trajectory of n time points against K test functions
 
 
 def stream_op(eng, op, n, d, order, flags, K=10):
@@ -66,6 +67,9 @@ def stream_op(eng, op, n, d, order, flags, K=10):
         return (lambda: eng.odeint(x, xi * 0.1, None, order, flags, K, 0.01, "euler")), n * 2 * f
     if op == "odeint_rk4":
         return (lambda: eng.odeint(x, xi * 0.1, None, order, flags, K, 0.01, "rk4")), n * 2 * f
+    if op == "weak_gram":                                # N1, sindy.py:362-381: [V; -V'] (2K, T) x [Theta | x] (T, p + d) on the fp64 MFMA
+        V, Vd = mk(K, n), mk(K, n)
+        return (lambda: eng.weak_gram(x, V, Vd, order, flags)), n * (f + 8 * K)
     if op == "gram_gather":
         S, m = 64, n // 128
         dx = mk(n, d)
@@ -141,7 +145,7 @@ def main():
         x2 = x.reshape(-1, a.d)
         fn = lambda: eng.theta(x2, a.order, a.flags)  # noqa: E731
         byt = pts * 4 * (a.d + p)
-    elif a.op in STREAM_OPS:
+    elif a.op in STREAM_OPS + EXTRA_OPS:
         fn, byt = stream_op(eng, a.op, pts, a.d, a.order, a.flags, a.K)
     else:
         raise SystemExit("unknown op")

@@ -59,10 +59,11 @@ def main():
         p = eng.lib_size(2, order, 0)
         xi = torch.randn(2, p).cuda() * 0.3
         loss, grad = torch.empty(1).cuda(), torch.empty(2, p).cuda()
-        for fused in (0, 1):
+        for fused in (0, 1, 2):
             for cap in (0, 64, 96, 128, 192):
                 os.environ["SYMODE_FUSED_FINALIZE"] = str(fused)
                 os.environ["SYMODE_SMALL_GRID"] = str(cap)
+                symode_amd.engine.reload_env()
                 us = ev_time(lambda: eng.loss_grad(x, dx, xi, None, order, out=(loss, grad)))
                 g = torch.cuda.CUDAGraph()
                 s = torch.cuda.Stream()
@@ -78,6 +79,7 @@ def main():
                 print(f"order {order} fused={fused} grid_cap={cap:3d}: eager {us:6.2f} us/call, graph of 20 back-to-back {gus:6.2f} us/call", flush=True)
         os.environ["SYMODE_FUSED_FINALIZE"] = "1"
         os.environ.pop("SYMODE_SMALL_GRID", None)
+        symode_amd.engine.reload_env()
         reg = SINDyRegression(2, order, False, False, threshold=0.05, device="cuda:0")
         for name, kw in (("zero-copy, one launch", dict(zero_copy=True, use_graph=False)),
                          ("copies + HIP graph", dict(zero_copy=False, use_graph=True)),

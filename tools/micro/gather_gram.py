@@ -1,5 +1,5 @@
 """Index-table Gram (seed sweeps over sorted subsamples of ONE data set) at BASELINE config[3]'s shape and a larger one:
-MFMA form (default) vs the vector-pipe form (SYMODE_GRAM_VALU_GATHER=1, read per call)."""
+MFMA form (default) vs the vector-pipe form (SYMODE_GRAM_VALU_GATHER=1; engine.reload_env() after every change)."""
 import os, sys
 import torch
 sys.path.insert(0, os.getcwd())
@@ -30,6 +30,7 @@ for N, S, frac, order in ((100000, 64, 0.5, 3), (100000, 64, 0.5, 5), (1000000, 
     row = []
     for env in ("0", "1"):
         os.environ["SYMODE_GRAM_VALU_GATHER"] = env
+        symode_amd.engine.reload_env()
         t = timeit(lambda: eng.aug_gram_gather(x, dx, idx, order, 0))
         row.append(f"gather valu={env}: {t:8.1f} us")
     t = timeit(lambda: eng.aug_gram(xs, dxs, order, 0))

@@ -1,4 +1,4 @@
-"""Single-problem reduction kernels vs N and the small-grid cap (SYMODE_SMALL_GRID is read per call)."""
+"""Single-problem reduction kernels vs N and the small-grid cap (SYMODE_SMALL_GRID; engine.reload_env() after every change)."""
 import os, sys
 import torch
 sys.path.insert(0, os.getcwd())
@@ -38,6 +38,7 @@ for N in (125000, 250000, 500000, 1000000, 2000000, 4000000, 16000000, 64000000)
             os.environ.pop("SYMODE_SMALL_GRID", None)
         else:
             os.environ["SYMODE_SMALL_GRID"] = cap
+        symode_amd.engine.reload_env()
         t1 = timeit(lambda: eng.loss_grad(x, dx, xi, None, order, 0, out=(lo, gr), ws=ws))
         t2 = timeit(lambda: eng.loss_grad_reversed(x[None], dx[None], gx, jg, xi[None], None, order, 0, w_sym=1.0, out=(l2, gr[None]), ws=ws))
         t3 = timeit(lambda: eng.symreg_reversed(x[None], gx, jg, xi[None], None, order, 0, out=(lo, gr[None]), ws=ws, inv_count=1.0 / (2 * N)))

@@ -145,7 +145,7 @@ def _fmt(value):
 
 # the parser's sections (parser_utils._MAIN_ARGS is declared in this order): one line of the file per section
 SECTIONS = [("task", "smoothing"), ("batch_size", "w_sym_reg"), ("latent_dim", "fix_laligan"), ("ae_arch", "batch_norm"),
-            ("repr", "keep_center"), ("use_original_x", "y_embed_dim"), ("include_sindy", "lstsq_driver"),
+            ("repr", "keep_center"), ("use_original_x", "y_embed_dim"), ("include_sindy", "torch_lbfgs"),
             ("pysr_subsample", "pysr_symmreg"), ("gpu", "seed")]
 
 
@@ -184,12 +184,17 @@ def main():
     sdir = os.path.join(PKG, "run_scripts")
     os.makedirs(sdir, exist_ok=True)
     for name, (module, cfg) in SCRIPTS.items():
+        st = CONFIGS[cfg]
+        # main_sweep takes the L-BFGS SINDy / EquivSINDy-c configs only (main_sweep.py: no latent, no symmetry regulariser)
+        sweepable = (module == "main" and st.get("sindy_optimizer", "lbfgs") == "lbfgs" and not st.get("use_latent", False)
+                     and float(st.get("w_sym_reg", 0.0)) == 0.0)
+        hint = ("# PYTHONPATH.  The whole loop as ONE process per GPU: python -m symode_amd.main_sweep --config "
+                f"{cfg} --n_seeds 50\n") if sweepable else "# PYTHONPATH.\n"
         with open(os.path.join(sdir, name + ".sh"), "w") as f:
             f.write("#!/bin/bash\n"
                     f"# Seeds 0-49 of {cfg}, one process per seed like the reference's script of the same name.\n"
                     "# Run from a directory that holds run_configs/ (this package directory does) with the repository root on\n"
-                    "# PYTHONPATH.  The whole loop as ONE process per GPU: python -m symode_amd.main_sweep --config "
-                    f"{cfg} --n_seeds 50\n"
+                    + hint +
                     "for i in {0..49}; do\n"
                     '    echo "Running seed $i"\n'
                     f'    python -m symode_amd.{module} --seed "$i" --config {cfg}\n'
