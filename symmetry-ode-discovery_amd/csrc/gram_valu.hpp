@@ -290,6 +290,11 @@ __global__ __launch_bounds__(BLOCK) void aug_gram_split_kernel(const float* __re
     if constexpr (NPART > 3) if (part == 3) gram_split_body<Lib, 3>(xs, ys, N, vec, tid, nthreads, dst, lds);
 }
 
+// (Round 3 tried the runs of a slab column as the WAVES of one workgroup instead: every wave evaluates and converts the
+// features of its own 64 points once, parks them as fp64 in LDS, and after a barrier adds its run over all NPART groups
+// -- 309 instead of 454 issue cycles per point and run on paper.  Measured 25 % SLOWER than this form on every shape
+// (1024 x 125 000 points at order 5: 49.9 against 66.2 G points/s; profiles/r03_gram_forms.txt): with two waves per SIMD
+// the 23 dependent ds_read_b64 per group and two barriers per step cost more than the library re-evaluation saves.  Removed.)
 // Sum the GX partial runs of problem s in fixed order and scatter into the dense symmetric (F, F) matrix.
 template <class Lib>
 __global__ __launch_bounds__(BLOCK) void gram_split_finalize_kernel(const double* __restrict__ part_ws, int GX,

@@ -22,7 +22,7 @@ constexpr int MAP_CHUNKS_PER_THREAD = SYMODE_MAP_CHUNKS;   // chunks a thread of
 // for the tests and tuning tools that compare two settings inside one process; no launch path calls getenv.
 struct Knobs {
     long max_grid, min_grid_x, map_grid, gram_grid, gram_valu_grid, small_grid, reduce_grid;
-    int fused_finalize, euler_stack, gram_valu, gram_split, gram_valu_gather, loss_grad_variant, segmented, row_split;
+    int fused_finalize, euler_stack, gram_valu, gram_split, gram_valu_gather, segmented, row_split;
 };
 
 inline Knobs read_knobs() {
@@ -41,7 +41,6 @@ inline Knobs read_knobs() {
     k.gram_valu = on("SYMODE_GRAM_VALU");
     k.gram_split = on("SYMODE_GRAM_SPLIT");
     k.gram_valu_gather = on("SYMODE_GRAM_VALU_GATHER");
-    k.loss_grad_variant = (int)num("SYMODE_LOSS_GRAD_VARIANT", -1);
     k.segmented = (int)num("SYMODE_SEGMENTED", 1);
     k.row_split = (int)num("SYMODE_ROW_SPLIT", 1);
     return k;
@@ -543,30 +542,29 @@ inline int fused_finalize_mode() { return (int)knobs().fused_finalize; }      //
 // ---------------------------------------------------------------------------------------
 // K1: fused Theta + residual + MSE + gradient                  (closure body + backward)
 // ---------------------------------------------------------------------------------------
-// VARIANT selects the streaming schedule (kept as a template knob for A/B runs on the GPU,
-// SYMODE_LOSS_GRAD_VARIANT; tools/ab_variants.py runs them in one gpurun call and checks bit-identity):
-//   0 plain grid-stride loop; 2 two chunks per step; 4 = 2 with non-temporal loads;
-//   5 = 4 with a register double buffer (next step's loads issued before this step's VALU work);
-//   7 = register ring of 4 chunk slots, each refilled right after use (6-8 KB in flight per wave) -- default;
-//   6 packed fp32 (below); 8 LDS-DMA ring.
-// Measured on MI355X, S = 2048 x 125000 points, d = 2 (round 1, algorithmic bytes / launch incl. finalize):
-//   order 5: 0 -> 4.8 TB/s, 4 -> 5.4, 5 -> 5.55, 7 -> 5.65 TB/s;  order 3: 0 -> 5.6, 4 -> 6.35, 5 and 7 -> 6.45 TB/s.
-// With the masked Xi in VGPRs the order-5 ring kernel needs 166 VGPRs (3 waves/SIMD); handing Xi to SGPRs (126 VGPRs,
-// 4 waves) measured 1.5 % slower -- an SGPR operand costs issue time -- and grid widths 4096-16384 measured the same:
-// nothing but the two pipes themselves is left to tune.
+// Streaming schedule: a register ring of chunk slots, each refilled right after use (points.hpp, chunk_ring).
+//   RING4 = true   the D = 2 libraries up to 64 coefficients -- every task the reference ships: four chunks of x and dx in
+//                  flight per lane (6-8 KB per wave); one big problem gives every workgroup its own contiguous slab;
+//   RING4 = false  everything else: two chunks in flight (D = 3: coalesced tile loads through the wave's LDS slab).
+// Round 1 measured the alternatives on MI355X (profiles/r01_ab_variants.txt; S = 2048 x 125 000 points, d = 2, algorithmic
+// bytes per launch): plain grid-stride loop 4.8 / 5.6 TB/s at order 5 / 3, two chunks per step with non-temporal loads
+// 5.4 / 6.35, a register double buffer 5.55 / 6.45, this ring 5.65 / 6.45; a packed-fp32 form (v_pk_fma_f32 over the two
+// equation rows: same roundings, half the instructions) and an LDS-DMA ring measured within 1 % of it -- gfx950 retires a
+// v_pk_fma_f32 in the time of two v_fma_f32 (profiles/r03_issue_probe.txt) -- and were removed in round 3.
+// With the masked Xi in VGPRs the order-5 kernel needs 166 VGPRs (3 waves/SIMD); handing Xi to SGPRs (126 VGPRs,
+// 4 waves) measured 1.5 % slower -- an SGPR operand costs issue time -- and grid widths 4096-16384 measured the same.
 // Why order 5 stops there: 108 VALU ops per point = 422 K wave-instructions per SIMD per launch, and a SIMD with 3
 // resident waves retires one every 1.23 ns (tools/micro/valu_rate.hip), i.e. 0.52 ms of VALU beside 0.52-0.64 ms of
 // HBM stream in a 0.73 ms launch: both pipes are > 70 % busy.  Forms with sched_barrier between points were slower or
 // equal; forcing 5-6 waves/SIMD (amdgpu_waves_per_eu) spills at order 5 (8-11x slower) and 4 waves is within 1.3 % of
 // the free allocation; -fno-slp-vectorize (Makefile) is worth 6 % at order 5: SLP-packed FMAs force the uniform
 // coefficients out of SGPRs into VGPR pairs.
-template <class Lib, int VARIANT>
+template <class Lib, bool RING4>
 __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, const float* __restrict__ dx, long N, bool vec,
                                                const float* __restrict__ xi, const float* __restrict__ mask,
                                                double* __restrict__ ws, const Finish& fin, const bool SEGMENTED) {
     vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
-    constexpr bool NT = (VARIANT == 4 || VARIANT == 5 || VARIANT == 7);
     const long s = blockIdx.y;
     const float* xs = x + s * N * D;
     const float* ys = dx + s * N * D;
@@ -590,389 +588,68 @@ __device__ __forceinline__ void loss_grad_body(const float* __restrict__ x, cons
 #pragma unroll
             for (int k = 0; k < P; ++k) acc[1 + j * P + k] = fmaf(r[j], th[k], acc[1 + j * P + k]);
     };
-    auto chunk = [&](const float4 (&vx)[NV], const float4 (&vy)[NV]) {
-        float xp[PPT][D], yp[PPT][D];
-        unpack_chunk<D>(vx, xp);
-        unpack_chunk<D>(vy, yp);
-        each_point<PPT>([&](auto i) { one(xp[i], yp[i]); });
-    };
     auto point = [&](long n) {
         float xp[D], yp[D];
         load_point<D>(xs, n, xp);
         load_point<D>(ys, n, yp);
         one(xp, yp);
     };
-
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
-    long nthreads = (long)gridDim.x * BLOCK;
-    if (vec) {
-        const long nchunks_all = N / PPT;
-        long nchunks = nchunks_all;
-        long c = tid;
-        if (SEGMENTED) {
-            // every workgroup streams its own contiguous slab of the problem (as the batched launches do)
-            const long per = (nchunks_all + gridDim.x - 1) / gridDim.x;
-            const long lo = (long)blockIdx.x * per;
-            nchunks = lo + per < nchunks_all ? lo + per : nchunks_all;
-            c = lo + threadIdx.x;
-            nthreads = BLOCK;
-        }
-        if constexpr (VARIANT == 5) {
-            // register double buffer: the next step's four 16-byte loads are issued before the current step's
-            // ~430 VALU ops, so a wave always has 4 KB in flight (addresses clamped: the tail over-reads in bounds)
-            if (nchunks_all > 0) {
-                const long lastc = nchunks_all - 1;
-                auto ld = [&](long cc, float4 (&vx)[NV], float4 (&vy)[NV]) {
-                    const long q = cc < lastc ? cc : lastc;
+    if constexpr (RING4) {
+        const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
+        if (vec) {
+            const long nchunks_all = N / PPT;
+            long nchunks = nchunks_all, c0 = tid, stride = (long)gridDim.x * BLOCK;
+            if (SEGMENTED) {
+                // every workgroup streams its own contiguous slab of the problem (as the batched launches do)
+                const long per = (nchunks_all + gridDim.x - 1) / gridDim.x;
+                const long lo = (long)blockIdx.x * per;
+                nchunks = lo + per < nchunks_all ? lo + per : nchunks_all;
+                c0 = lo + threadIdx.x;
+                stride = BLOCK;
+            }
+            chunk_ring<4, 2 * NV>(
+                nchunks, c0, stride,
+                [&](long q, float4 (&slot)[2 * NV]) {
+                    float4 vx[NV], vy[NV];
                     load_chunk_raw<D, true>(xs, q, vx);
                     load_chunk_raw<D, true>(ys, q, vy);
-                };
-                float4 ax[NV], ay[NV], bx[NV], by[NV];
-                ld(c, ax, ay);
-                ld(c + nthreads, bx, by);
-                for (; c + nthreads < nchunks; c += 2 * nthreads) {
-                    float4 nax[NV], nay[NV], nbx[NV], nby[NV];
-                    ld(c + 2 * nthreads, nax, nay);
-                    ld(c + 3 * nthreads, nbx, nby);
-                    chunk(ax, ay);
-                    chunk(bx, by);
 #pragma unroll
                     for (int i = 0; i < NV; ++i) {
-                        ax[i] = nax[i];
-                        ay[i] = nay[i];
-                        bx[i] = nbx[i];
-                        by[i] = nby[i];
+                        slot[i] = vx[i];
+                        slot[NV + i] = vy[i];
                     }
-                }
-                if (c < nchunks) chunk(ax, ay);
-            }
-        } else if constexpr (VARIANT == 7) {
-            // register ring of R chunk slots, each refilled right after it is consumed: R-1 chunks (x and dx) always
-            // in flight per lane, no register copies (the slot loop is unrolled), same chunk order as the other forms
-            constexpr int R = 4;
-            if (nchunks_all > 0) {
-                const long lastc = nchunks_all - 1;
-                auto ld = [&](long cc, float4 (&vx)[NV], float4 (&vy)[NV]) {
-                    const long q = cc < lastc ? cc : lastc;
-                    load_chunk_raw<D, true>(xs, q, vx);
-                    load_chunk_raw<D, true>(ys, q, vy);
-                };
-                float4 rx[R][NV], ry[R][NV];
-#pragma unroll
-                for (int k = 0; k < R; ++k) ld(c + k * nthreads, rx[k], ry[k]);
-                for (; c + (R - 1) * nthreads < nchunks; c += R * nthreads) {
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        chunk(rx[k], ry[k]);
-                        ld(c + (R + k) * nthreads, rx[k], ry[k]);
-                        __builtin_amdgcn_sched_barrier(0);       // keep the refill here: the scheduler would sink all R to the loop end
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < R; ++k)
-                    if (c + k * nthreads < nchunks) chunk(rx[k], ry[k]);
-            }
-        } else if constexpr ((VARIANT == 2 || VARIANT == 4) && D == 3) {
-            // 12-byte points: coalesced tile loads + wave-private LDS redistribution while the wave is whole
-            // (points.hpp); ragged waves fall back to the strided per-lane loads
-            __shared__ float4 slab3[BLOCK / WAVE][3 * WAVE];
-            const int lane = threadIdx.x & (WAVE - 1);
-            float4* slab = slab3[threadIdx.x / WAVE];
-            for (; c + nthreads < nchunks; c += 2 * nthreads) {
-                float4 ax[NV], ay[NV], bx[NV], by[NV];
-                if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {
-                    float4 tax[NV], tay[NV], tbx[NV], tby[NV];
-                    const long c0 = c - lane;
-                    load_tile3_raw<NT>(xs, c0, lane, tax);
-                    load_tile3_raw<NT>(ys, c0, lane, tay);
-                    load_tile3_raw<NT>(xs, c0 + nthreads, lane, tbx);
-                    load_tile3_raw<NT>(ys, c0 + nthreads, lane, tby);
-                    exchange_tile3(tax, ax, slab, lane);
-                    exchange_tile3(tay, ay, slab, lane);
-                    exchange_tile3(tbx, bx, slab, lane);
-                    exchange_tile3(tby, by, slab, lane);
-                } else {
-                    load_chunk_raw<D, NT>(xs, c, ax);
-                    load_chunk_raw<D, NT>(ys, c, ay);
-                    load_chunk_raw<D, NT>(xs, c + nthreads, bx);
-                    load_chunk_raw<D, NT>(ys, c + nthreads, by);
-                }
-                chunk(ax, ay);
-                chunk(bx, by);
-            }
-            if (c < nchunks) {
-                float4 ax[NV], ay[NV];
-                load_chunk_raw<D, NT>(xs, c, ax);
-                load_chunk_raw<D, NT>(ys, c, ay);
-                chunk(ax, ay);
-            }
-        } else if constexpr (VARIANT == 2 || VARIANT == 4) {
-            for (; c + nthreads < nchunks; c += 2 * nthreads) {
-                float4 ax[NV], ay[NV], bx[NV], by[NV];
-                load_chunk_raw<D, NT>(xs, c, ax);
-                load_chunk_raw<D, NT>(ys, c, ay);
-                load_chunk_raw<D, NT>(xs, c + nthreads, bx);
-                load_chunk_raw<D, NT>(ys, c + nthreads, by);
-                chunk(ax, ay);
-                chunk(bx, by);
-            }
-            if (c < nchunks) {
-                float4 ax[NV], ay[NV];
-                load_chunk_raw<D, NT>(xs, c, ax);
-                load_chunk_raw<D, NT>(ys, c, ay);
-                chunk(ax, ay);
-            }
-        } else if constexpr (VARIANT == 8) {
-            // LDS-DMA ring: every lane's next NS-1 chunks are in flight as global_load_lds (no VGPRs),
-            // parked at ring[stage][array][thread]; a lane only ever reads back its own slots, so the
-            // only synchronisation is the issuing wave's counted vmcnt (no barrier).
-            constexpr int NS = 4, PER = 2 * NV;                 // DMA instructions per wave per stage
-            __shared__ float4 ring[NS][PER][BLOCK];
-            const int wbase = (threadIdx.x / WAVE) * WAVE;
-            const float4* gx = reinterpret_cast<const float4*>(xs);
-            const float4* gy = reinterpret_cast<const float4*>(ys);
-            const long last = nchunks - 1;
-            auto issue = [&](int st, long cc) {
-                const long cl = cc < last ? cc : last;           // clamp: keeps the vmcnt arithmetic uniform
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(gx + cl * NV + i),
-                        (__attribute__((address_space(3))) void*)&ring[st][i][wbase], 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(gy + cl * NV + i),
-                        (__attribute__((address_space(3))) void*)&ring[st][NV + i][wbase], 16, 0, 0);
-                }
-            };
-            const long c0 = c - threadIdx.x;                     // block-uniform trip count (first chunk of this workgroup)
-            const long iters = nchunks > c0 ? (nchunks - c0 + nthreads - 1) / nthreads : 0;
-            if (iters > 0 && nchunks > 0) {
-#pragma unroll
-                for (int st = 0; st < NS - 1; ++st) issue(st, c + (long)st * nthreads);
-                for (long it = 0; it < iters; ++it) {
-                    const int st = (int)(it % NS);
-                    issue((int)((it + NS - 1) % NS), c + (NS - 1) * nthreads);
-                    // all but the youngest (NS-1) stages' DMAs have landed -> stage `st` is readable
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (NS - 1)) : "memory");
-                    float4 ax[NV], ay[NV];
+                },
+                [&](long, const float4 (&slot)[2 * NV]) {
+                    float4 vx[NV], vy[NV];
 #pragma unroll
                     for (int i = 0; i < NV; ++i) {
-                        const unsigned ax_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)&ring[st][i][threadIdx.x];
-                        const unsigned ay_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)&ring[st][NV + i][threadIdx.x];
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(ax[i]) : "v"(ax_addr) : "memory");
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(ay[i]) : "v"(ay_addr) : "memory");
+                        vx[i] = slot[i];
+                        vy[i] = slot[NV + i];
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (c < nchunks) chunk(ax, ay);
-                    c += nthreads;
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches
-            }
+                    float xp[PPT][D], yp[PPT][D];
+                    unpack_chunk<D>(vx, xp);
+                    unpack_chunk<D>(vy, yp);
+                    each_point<PPT>([&](auto i) { one(xp[i], yp[i]); });
+                });
+            const long n = nchunks_all * PPT + tid;
+            if (n < N) point(n);
         } else {
-            for (; c < nchunks; c += nthreads) {
-                float4 ax[NV], ay[NV];
-                load_chunk_raw<D, false>(xs, c, ax);
-                load_chunk_raw<D, false>(ys, c, ay);
-                chunk(ax, ay);
-            }
+            for (long n = tid; n < N; n += (long)gridDim.x * BLOCK) point(n);
         }
-        const long n = nchunks_all * PPT + tid;
-        if (n < N) point(n);
     } else {
-        for (long n = tid; n < N; n += nthreads) point(n);
+        const float* const arrs[2] = {xs, ys};
+        for_each_chunk_ring<D, BLOCK, 2, 2>(
+            N, vec, arrs, [&](long, float (&o)[2][PPT][D]) { each_point<PPT>([&](auto i) { one(o[0][i], o[1][i]); }); }, point);
     }
     emit_partials<NACC>(acc, ws, fin);
 }
 
-// Packed-fp32 form of K1 (VARIANT 6, D <= 2; an A/B knob, not the default).
-// A lane carries two points (a, b) per step as the halves of 64-bit register pairs:
-//   Theta      th2[k] = (th_a[k], th_b[k])                         one v_pk_mul_f32 per column for both points
-//   residual   r_a (rows 2jp, 2jp+1) = sum_k w2[jp][k] * th_a[k]   v_pk_fma_f32, th broadcast by op_sel
-//   gradient   acc2[jp][k] += r_a * th_a[k]; += r_b * th_b[k]      v_pk_fma_f32 onto a (row pair, column) accumulator
-// which halves the VALU instruction count (228 instead of 432 per 4 points at order 5) without more accumulator
-// registers.  Every fp32 value is rounded exactly as in the scalar form and added in the same order (a then b), so
-// results are bit-identical for even D (checked on the GPU, tools/ab_variants.py); for odd D the last row keeps
-// separate a/b accumulators that are added once at the end.
-// Measured on MI355X (S = 2048 x 125000 points, d = 2): orders 2-5 within 1 % of the scalar form (order 5: 0.742 vs
-// 0.742 ms).  gfx950's SIMD retires a wave64 v_fma_f32 in 2 cycles and a v_pk_fma_f32 in 4, i.e. the same
-// 64 FLOP/clk/SIMD: packing saves issue slots, not VALU time, and issue slots are not what limits this kernel.
-template <class Lib>
-__device__ __forceinline__ void loss_grad_body_packed(const float* __restrict__ x, const float* __restrict__ dx, long N,
-                                                      bool vec, const float* __restrict__ xi,
-                                                      const float* __restrict__ mask, double* __restrict__ ws,
-                                                      const Finish& fin, const bool SEGMENTED) {
-    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
-    constexpr int D = Lib::D, P = Lib::P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV, NACC = 1 + D * P;
-    constexpr int JP = D / 2;
-    constexpr bool ODD = (D % 2) != 0;
-    constexpr int JL = D - 1;                 // the unpaired row when D is odd
-    const long s = blockIdx.y;
-    const float* xs = x + s * N * D;
-    const float* ys = dx + s * N * D;
-    float w[D * P];
-    load_xi<Lib>(xi, mask, s, w);
-    f2 acc2[JP > 0 ? JP : 1][P];              // rows (2jp, 2jp+1) x column k
-    f2 accl[P];                               // odd D: row JL, (points a, points b) kept apart
-    float acc0 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-#pragma unroll
-        for (int jp = 0; jp < JP; ++jp) acc2[jp][k] = splat(0.0f);
-        accl[k] = splat(0.0f);
-    }
-
-    auto pair = [&](const float (&xa)[D], const float (&ya)[D], const float (&xb)[D], const float (&yb)[D]) {
-        f2 x2[D], th2[P];
-#pragma unroll
-        for (int v = 0; v < D; ++v) x2[v] = f2{xa[v], xb[v]};
-        Lib::eval2(x2, th2);
-        f2 ra[JP > 0 ? JP : 1], rb[JP > 0 ? JP : 1], rl = splat(0.0f);
-#pragma unroll
-        for (int jp = 0; jp < JP; ++jp) {
-            f2 sa = splat(0.0f), sb = splat(0.0f);
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const f2 w2 = f2{w[(2 * jp) * P + k], w[(2 * jp + 1) * P + k]};
-                sa = fma2(w2, splat_lo(th2[k]), sa);
-                sb = fma2(w2, splat_hi(th2[k]), sb);
-            }
-            ra[jp] = sa - f2{ya[2 * jp], ya[2 * jp + 1]};
-            rb[jp] = sb - f2{yb[2 * jp], yb[2 * jp + 1]};
-        }
-        if constexpr (ODD) {
-#pragma unroll
-            for (int k = 0; k < P; ++k) rl = fma2(splat(w[JL * P + k]), th2[k], rl);
-            rl -= f2{ya[JL], yb[JL]};
-        }
-        // sum of squares in the scalar form's order: point a rows 0..D-1, then point b
-#pragma unroll
-        for (int jp = 0; jp < JP; ++jp) {
-            acc0 = fmaf(ra[jp].x, ra[jp].x, acc0);
-            acc0 = fmaf(ra[jp].y, ra[jp].y, acc0);
-        }
-        if constexpr (ODD) acc0 = fmaf(rl.x, rl.x, acc0);
-#pragma unroll
-        for (int jp = 0; jp < JP; ++jp) {
-            acc0 = fmaf(rb[jp].x, rb[jp].x, acc0);
-            acc0 = fmaf(rb[jp].y, rb[jp].y, acc0);
-        }
-        if constexpr (ODD) acc0 = fmaf(rl.y, rl.y, acc0);
-#pragma unroll
-        for (int jp = 0; jp < JP; ++jp)
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                acc2[jp][k] = fma2(ra[jp], splat_lo(th2[k]), acc2[jp][k]);
-                acc2[jp][k] = fma2(rb[jp], splat_hi(th2[k]), acc2[jp][k]);
-            }
-        if constexpr (ODD) {
-#pragma unroll
-            for (int k = 0; k < P; ++k) accl[k] = fma2(rl, th2[k], accl[k]);
-        }
-    };
-    auto one = [&](const float (&xp)[D], const float (&yp)[D]) {      // ragged tails: scalar ops on the low halves
-        float th[P], r[D];
-        Lib::eval(xp, th);
-        apply_xi<Lib>(w, th, r);
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            r[j] -= yp[j];
-            acc0 = fmaf(r[j], r[j], acc0);
-        }
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-#pragma unroll
-            for (int jp = 0; jp < JP; ++jp) acc2[jp][k] = fma2(f2{r[2 * jp], r[2 * jp + 1]}, splat(th[k]), acc2[jp][k]);
-            if constexpr (ODD) accl[k].x = fmaf(r[JL], th[k], accl[k].x);
-        }
-    };
-    auto chunk = [&](const float4 (&vx)[NV], const float4 (&vy)[NV]) {
-        float xp[PPT][D], yp[PPT][D];
-        unpack_chunk<D>(vx, xp);
-        unpack_chunk<D>(vy, yp);
-        if constexpr (PPT >= 2) {
-#pragma unroll
-            for (int i = 0; i < PPT; i += 2) pair(xp[i], yp[i], xp[i + 1], yp[i + 1]);
-        } else {
-            one(xp[0], yp[0]);
-        }
-    };
-    auto chunk2 = [&](const float4 (&ax)[NV], const float4 (&ay)[NV], const float4 (&bx)[NV], const float4 (&by)[NV]) {
-        if constexpr (PPT >= 2) {
-            chunk(ax, ay);
-            chunk(bx, by);
-        } else {                                                      // D = 4: the pair spans the step's two chunks
-            float xa[1][D], ya[1][D], xb[1][D], yb[1][D];
-            unpack_chunk<D>(ax, xa);
-            unpack_chunk<D>(ay, ya);
-            unpack_chunk<D>(bx, xb);
-            unpack_chunk<D>(by, yb);
-            pair(xa[0], ya[0], xb[0], yb[0]);
-        }
-    };
-    auto point = [&](long n) {
-        float xp[D], yp[D];
-        load_point<D>(xs, n, xp);
-        load_point<D>(ys, n, yp);
-        one(xp, yp);
-    };
-
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
-    long nthreads = (long)gridDim.x * BLOCK;
-    if (vec) {
-        const long nchunks_all = N / PPT;
-        long nchunks = nchunks_all;
-        long c = tid;
-        if (SEGMENTED) {
-            const long per = (nchunks_all + gridDim.x - 1) / gridDim.x;
-            const long lo = (long)blockIdx.x * per;
-            nchunks = lo + per < nchunks_all ? lo + per : nchunks_all;
-            c = lo + threadIdx.x;
-            nthreads = BLOCK;
-        }
-        for (; c + nthreads < nchunks; c += 2 * nthreads) {
-            float4 ax[NV], ay[NV], bx[NV], by[NV];
-            load_chunk_raw<D, true>(xs, c, ax);
-            load_chunk_raw<D, true>(ys, c, ay);
-            load_chunk_raw<D, true>(xs, c + nthreads, bx);
-            load_chunk_raw<D, true>(ys, c + nthreads, by);
-            chunk2(ax, ay, bx, by);
-        }
-        if (c < nchunks) {
-            float4 ax[NV], ay[NV];
-            load_chunk_raw<D, true>(xs, c, ax);
-            load_chunk_raw<D, true>(ys, c, ay);
-            chunk(ax, ay);
-        }
-        const long n = nchunks_all * PPT + tid;
-        if (n < N) point(n);
-    } else {
-        for (long n = tid; n < N; n += nthreads) point(n);
-    }
-    float acc[NACC];
-    acc[0] = acc0;
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-#pragma unroll
-        for (int jp = 0; jp < JP; ++jp) {
-            acc[1 + (2 * jp) * P + k] = acc2[jp][k].x;
-            acc[1 + (2 * jp + 1) * P + k] = acc2[jp][k].y;
-        }
-        if constexpr (ODD) acc[1 + JL * P + k] = accl[k].x + accl[k].y;
-    }
-    emit_partials<NACC>(acc, ws, fin);
-}
-
-template <class Lib, int VARIANT>
+template <class Lib, bool RING4>
 __global__ __launch_bounds__(BLOCK) void loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                           long N, bool vec, const float* __restrict__ xi,
                                                           const float* __restrict__ mask, double* __restrict__ ws,
                                                           Finish fin, bool segmented) {
-    vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
-    if constexpr (VARIANT == 6)
-        loss_grad_body_packed<Lib>(x, dx, N, vec, xi, mask, ws, fin, segmented);
-    else
-        loss_grad_body<Lib, VARIANT>(x, dx, N, vec, xi, mask, ws, fin, segmented);
+    loss_grad_body<Lib, RING4>(x, dx, N, vec, xi, mask, ws, fin, segmented);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1756,7 +1433,6 @@ hipError_t launch_odeint(const float* x, long n, const float* xi, const float* m
     return hipSuccess;
 }
 
-inline int loss_grad_variant() { return knobs().loss_grad_variant; }          // -1: the library's own default
 
 // ---------------------------------------------------------------------------------------
 // K1 for large libraries (D * P > SGPR_XI_MAX: d = 3 order 4, d = 4 order 3, sine/exp variants): one ROW per wave.
@@ -1865,7 +1541,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // 2048 blocks over 768 resident slots (order 5) left a 2/3-empty last round (-20 % at N = 2^27).
     static const int resident = [] {
         int nb = 0, cu = 256, dev = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, ((Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX)) ? 7 : 4>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loss_grad_kernel<Lib, (Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX)>, BLOCK, 0) != hipSuccess || nb < 1) nb = 2;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
         return nb * cu;
     }();
@@ -1874,9 +1550,8 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
     // contiguous slab per workgroup: 1 = for one big problem, 2 = also inside every problem of a batch
     const bool seg = (seg_env == 1 && S == 1 && gx >= 64) || (seg_env == 2 && gx >= 2);
     const dim3 grid(gx, (unsigned)S), block(BLOCK);
-    // The register-ring / prefetch / packed forms pay only where the library leaves registers for them: d = 2 (every
-    // task the reference ships).  Mid-size libraries keep the two-chunk form, the largest ones (D*P > SGPR_XI_MAX) the
-    // row-per-wave kernel; the experimental variants are not even instantiated for them.
+    // The four-slot ring pays where the library leaves registers for it: d = 2 (every task the reference ships).  Mid-size
+    // libraries run two slots, the largest ones (D*P > SGPR_XI_MAX) the row-per-wave kernel.
     constexpr bool TUNED = (Lib::D == 2) && (Lib::D * Lib::P <= SGPR_XI_MAX);
     constexpr bool ROWS = (Lib::D >= 2) && (Lib::D * Lib::P > SGPR_XI_MAX);
     const int rows_env = knobs().row_split;
@@ -1891,27 +1566,7 @@ hipError_t launch_loss_grad(const float* x, const float* dx, long S, long n, con
             return launch_finalize(fin, part, S, gx, NACC, st);
         }
     }
-    int variant = loss_grad_variant();
-    if (variant < 0) variant = TUNED ? 7 : 4;
-    if (!TUNED && variant != 0) variant = 4;
-    if constexpr (TUNED) {
-        switch (variant) {
-#ifdef SYMODE_AB_VARIANTS        // the measured-and-rejected schedules (make AB=1; tools/ab_variants.py): not in the default build
-            case 2: loss_grad_kernel<Lib, 2><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            case 5: loss_grad_kernel<Lib, 5><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            case 6: loss_grad_kernel<Lib, 6><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            case 8: loss_grad_kernel<Lib, 8><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-#endif
-            case 4: loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            case 0: loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-            default: loss_grad_kernel<Lib, 7><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg); break;
-        }
-    } else {
-        if (variant == 4)
-            loss_grad_kernel<Lib, 4><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg);
-        else
-            loss_grad_kernel<Lib, 0><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg);
-    }
+    loss_grad_kernel<Lib, TUNED><<<grid, block, 0, st>>>(x, dx, n, vec, xi, mask, part, fin, seg && TUNED);
     SYMODE_LAUNCH_CHECK();
     return launch_finalize(fin, part, S, gx, NACC, st);
 }

@@ -18,13 +18,6 @@ constexpr int FLAG_EXP = 2;    // include_exp   (sindy.py:76-77)
 
 constexpr int MAX_D = 4;
 
-// Two points side by side in one 64-bit register pair: gfx950's packed fp32 VALU ops (v_pk_mul_f32, v_pk_fma_f32)
-// retire both halves per issue slot, and their op_sel modifiers broadcast either half for free.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 splat_lo(f2 a) { return __builtin_shufflevector(a, a, 0, 0); }
-__device__ __forceinline__ f2 splat_hi(f2 a) { return __builtin_shufflevector(a, a, 1, 1); }
-__device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 constexpr int MAX_ORDER = 5;
 
 constexpr long binom(int n, int k) {
@@ -91,22 +84,6 @@ struct Library {
         if constexpr (EXP) {
 #pragma unroll
             for (int i = 0; i < D; ++i) th[EXP0 + i] = expf(x[i]);
-        }
-    }
-
-    // Theta of two points at once (lo = point a, hi = point b): the same left-to-right products, one
-    // v_pk_mul_f32 per column pair, so each half is bit-identical to eval().
-    static __device__ __forceinline__ void eval2(const f2 (&x)[D], f2 (&th)[P]) {
-        th[0] = splat(1.0f);
-#pragma unroll
-        for (int t = 1; t < NP; ++t) th[t] = th[tab.parent[t]] * x[tab.var[t]];
-        if constexpr (SINE) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) th[SIN0 + i] = f2{sinf(x[i].x), sinf(x[i].y)};
-        }
-        if constexpr (EXP) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) th[EXP0 + i] = f2{expf(x[i].x), expf(x[i].y)};
         }
     }
 

@@ -62,16 +62,24 @@ __global__ __launch_bounds__(BLOCK) void weak_gram_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < F; ++k) feat[k] = 0.0f;
         }
+        // the slab's 16 A operands (test function `row` at 4 time points per MFMA step) are requested up front: at
+        // T = 10^4 a wave sees one or two slabs, and sixteen dependent global loads in the MFMA loop WERE the launch
+        // (24.6 us for 10^4 points x 50 test functions before, profiles/r03_weak_gram_kernel_stats.txt)
+        float av[WAVE / 4];
+#pragma unroll
+        for (int ks = 0; ks < WAVE / 4; ++ks) {
+            const long tt = slab * WAVE + 4 * ks + (lane >> 4);
+            av[ks] = (arow != nullptr && tt < T) ? arow[tt] : 0.0f;
+        }
         __builtin_amdgcn_wave_barrier();                 // the previous slab's operand reads are done (wave-private slab)
 #pragma unroll
         for (int k = 0; k < F; ++k) my[k * PS + lane] = feat[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
+#pragma unroll
         for (int ks = 0; ks < WAVE / 4; ++ks) {
-            const long tt = slab * WAVE + 4 * ks + (lane >> 4);
-            const double a = (arow != nullptr && tt < T) ? (double)(sign * arow[tt]) : 0.0;
+            const double a = (double)(sign * av[ks]);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const double b = (double)my[(16 * c + (lane & 15)) * PS + 4 * ks + (lane >> 4)];
@@ -106,8 +114,17 @@ __global__ __launch_bounds__(BLOCK) void weak_gram_finalize_kernel(const double*
     constexpr int CT = W::CT;
     const int rt = blockIdx.x, e = threadIdx.x, row = e >> 4, col = e & 15;
     for (int c = 0; c < CT; ++c) {
+        const double* src = part + (long)rt * gx * (CT * 256) + c * 256 + e;
         double v = 0.0;
-        for (int g = 0; g < gx; ++g) v += part[((long)rt * gx + g) * (CT * 256) + c * 256 + e];
+        int g = 0;
+        for (; g + 8 <= gx; g += 8) {                    // eight partials in flight, added in order (40-64 of them at T >= 10^4)
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(long)(g + u) * (CT * 256)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; g < gx; ++g) v += src[(long)g * (CT * 256)];
         out[(long)(16 * rt + row) * (CT * 16) + 16 * c + col] = v;
     }
 }

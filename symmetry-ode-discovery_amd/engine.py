@@ -175,8 +175,8 @@ class HipEngine:
             raise SymodeError(f"library d={d} order={order} flags={flags} is not compiled into libsymode_hip")
         return p
 
-    def workspace(self, device, d, order, flags, n_problems, n) -> torch.Tensor:
-        need = self.lib.symode_workspace_bytes(d, order, flags, n_problems, n)
+    def workspace(self, device, d, order, flags, n_problems, n, min_bytes=0) -> torch.Tensor:
+        need = max(self.lib.symode_workspace_bytes(d, order, flags, n_problems, n), min_bytes)
         dev = torch.device(device)
         key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)   # one scratch per (device, stream)
         ws = self._ws.get(key)
@@ -457,7 +457,9 @@ class HipEngine:
         p = self.lib_size(d, order, flags)
         R, C = 16 * ((2 * K + 15) // 16), 16 * ((p + d + 15) // 16)
         out = torch.empty(R, C, dtype=torch.float64, device=x.device)
-        ws = self.workspace(x.device, d, order, flags, 1, T)
+        # room for the widest launch (64 time slabs x row tiles x column tiles of 256 fp64 partials behind the header):
+        # a scratch sized for the closures alone made the library halve the grid to 5 workgroups at T = 10^4
+        ws = self.workspace(x.device, d, order, flags, 1, T, min_bytes=8 * (8 + 32768 + 64 * (R // 16) * (C // 16) * 256) + 4096)
         self._check(self.lib.symode_weak_gram(self._ptr(x), T, d, order, flags, self._ptr(V), self._ptr(V_drv), K, self._ptr(out),
                                               self._ptr(ws), ws.numel() * 8, self._stream(x)), "symode_weak_gram")
         return out[:K, :p], out[K:2 * K, p:p + d]

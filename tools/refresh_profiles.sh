@@ -31,19 +31,19 @@ export SYMODE_GRAM_VALU=0      # order 3 (F = 12) takes the vector-pipe Gram by 
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma3 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 3 --reps 3 > /dev/null 2>&1
 unset SYMODE_GRAM_VALU
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_gvalu -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 3 --reps 3 > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 3 > /dev/null 2>&1 && echo "mfma done"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_gvalu5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 3 > /dev/null 2>&1 && echo "gram pmc done"
 cd "$R"
 python tools/rocprof_summary.py /tmp/prof_bench > "$O/${TAG}_bench_kernel_stats.txt"
 python tools/rocprof_summary.py /tmp/prof_ops > "$O/${TAG}_ops_kernel_stats.txt"
-python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024000000 "closure_reversed=symreg_reversed_kernel<symode::Library<2, 5, 0>, true>" > "$O/pmc_traffic.json"
-python tools/pmc_traffic.py /tmp/pmc_fetch2 /tmp/pmc_write2 1024000000 loss_grad=loss_grad_kernel "symreg_reversed=symreg_reversed_kernel<symode::Library<2, 5, 0>, false>" > "$O/pmc_traffic_two_launch.json"
+python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024000000 "closure_reversed=symreg_reversed_kernel<symode::Library<2, 5, 0>, true" > "$O/pmc_traffic.json"
+python tools/pmc_traffic.py /tmp/pmc_fetch2 /tmp/pmc_write2 1024000000 loss_grad=loss_grad_kernel "symreg_reversed=symreg_reversed_kernel<symode::Library<2, 5, 0>, false" > "$O/pmc_traffic_two_launch.json"
 python tools/pmc_valu.py /tmp/pmc_valu euler_jvp_kernel euler_jvp_vjp_kernel odeint_kernel symreg_linear_kernel loss_grad_kernel symreg_reversed_kernel "symode::vjp_kernel" "symode::jvp_vjp_kernel" > "$O/${TAG}_valu_pmc.json"
 python tools/pmc_traffic.py /tmp/pmc_fetch_vjp /tmp/pmc_write_vjp 67108864 "vjp_grad_x=symode::vjp_kernel" > "$O/pmc_traffic_vjp.json"
 python tools/rocprof_summary.py /tmp/prof_weak > "$O/${TAG}_weak_gram_kernel_stats.txt"
 python tools/rocprof_summary.py /tmp/prof_weak_big >> "$O/${TAG}_weak_gram_kernel_stats.txt"
 python tools/pmc_mfma.py /tmp/pmc_mfma3 aug_gram_kernel > "$O/${TAG}_gram_o3_mfma_pmc.json"
 python tools/pmc_valu.py /tmp/pmc_gvalu aug_gram_valu_kernel > "$O/${TAG}_gram_o3_valu_pmc.json"
-python tools/pmc_mfma.py /tmp/pmc_mfma5 aug_gram_kernel > "$O/${TAG}_gram_o5_mfma_pmc.json"
+python tools/pmc_valu.py /tmp/pmc_gvalu5 aug_gram_split_kernel > "$O/${TAG}_gram_o5_split_pmc.json"
 python tools/latency_bench.py --orders 3 5 > "$O/${TAG}_latency.txt" 2>&1
 head -6 "$O/${TAG}_bench_kernel_stats.txt"
 cat "$O/pmc_traffic.json" | head -30
