@@ -938,13 +938,50 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
             chunk_g(th, h, ng, nj, zero);
         }
     };
-    if (vec && n_g > 0) {
+    if constexpr (D == 3) {
+        // 12-byte points and 36-byte Jacobians: whole waves fetch their tiles coalesced and redistribute through a
+        // wave-private LDS slab (points.hpp, exchange_tile); ragged waves and the tail keep the per-lane loads
+        if (vec && n_g > 0) {
+            __shared__ float4 slab3[BLOCK / WAVE][NVJ * WAVE];
+            const int lane = threadIdx.x & (WAVE - 1);
+            float4* slab = slab3[threadIdx.x / WAVE];
+            const long nchunks = N / PPT;
+            for (long c = tid;; c += nthreads) {
+                const bool in = c < nchunks;
+                const unsigned long long live = __builtin_amdgcn_ballot_w64(in);
+                if (live == 0ull) break;
+                float4 ax[NV], ay[NV], ag[NV], aj[NVJ];
+                if (live == ~0ull) {
+                    const long c0 = c - lane;
+                    float4 tx[NV], ty[NV], tg[NV], tj[NVJ];
+                    load_tile_raw<NV, true>(xs, c0, lane, tx);
+                    if constexpr (MSE) load_tile_raw<NV, true>(ys, c0, lane, ty);
+                    load_tile_raw<NV, true>(gs, c0, lane, tg);
+                    load_tile_raw<NVJ, true>(js, c0, lane, tj);
+                    exchange_tile<NV>(tx, ax, slab, lane);
+                    if constexpr (MSE) exchange_tile<NV>(ty, ay, slab, lane);
+                    exchange_tile<NV>(tg, ag, slab, lane);
+                    exchange_tile<NVJ>(tj, aj, slab, lane);
+                } else if (in) {
+                    load_chunk_raw<D, true>(xs, c, ax);
+                    if constexpr (MSE) load_chunk_raw<D, true>(ys, c, ay);
+                    load_chunk_raw<D, true>(gs, c, ag);
+                    load_j(js, c, aj);
+                }
+                if (in) chunk_all(c, ax, ay, ag, aj);
+            }
+            const long n = nchunks * PPT + tid;
+            if (n < N) point(n);
+        } else {
+            for (long n = tid; n < N; n += nthreads) point(n);
+        }
+    } else if (vec && n_g > 0) {
         // register ring: RING chunks of x, (dx,) g(x), J_g of the first group element in flight per lane, a slot refilled
         // as soon as its chunk has been consumed (closure_ab: one 2^26-point problem 334 -> 325 us at order 3, the fused
         // closure at order 5 470 -> 442 us; the batched bench shape is VALU / HBM co-limited either way)
         constexpr int NVT = (MSE ? 3 : 2) * NV + NVJ, OY = NV, OG = (MSE ? 2 : 1) * NV, OJ = OG + NV;
         const long nchunks = N / PPT;
-        chunk_ring<(D == 3 ? 1 : RING), NVT>(       // D = 3: a slot is 15-18 vectors (60-72 VGPRs), one chunk in flight
+        chunk_ring<RING, NVT>(
             nchunks, tid, nthreads,
             [&](long q, float4 (&slot)[NVT]) {
                 float4 tx[NV], tg[NV], tj[NVJ];

@@ -71,6 +71,37 @@ __device__ __forceinline__ void exchange_tile3(const float4 (&t)[3], float4 (&v)
     __builtin_amdgcn_wave_barrier();                     // the next exchange reuses the slab (a wave's LDS operations run in order)
 }
 
+// The same for any chunk of NVEC 16-byte vectors per lane (the regulariser's J_g at D = 3: 9 vectors = 144 bytes per lane,
+// which as per-lane loads touch ~9x the lines they use and thrash the 32 KB L1 with 8-12 waves per CU): the wave fetches
+// its 64 NVEC-vector tile coalesced -- lane l takes vectors l, 64 + l, ... -- and reads its own chunk back from a
+// wave-private slab of 64 NVEC vectors.  ds_read_b128 at a lane stride of NVEC vectors is conflict-free for odd NVEC.
+template <int NVEC, bool NT>
+__device__ __forceinline__ void load_tile_raw(const float* __restrict__ a, long c0, int lane, float4 (&t)[NVEC]) {
+    const float4* q = reinterpret_cast<const float4*>(a) + c0 * NVEC + lane;
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+        if constexpr (NT) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v u = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q + 64 * i));
+            t[i] = make_float4(u.x, u.y, u.z, u.w);
+        } else {
+            t[i] = q[64 * i];
+        }
+    }
+}
+
+template <int NVEC>
+__device__ __forceinline__ void exchange_tile(const float4 (&t)[NVEC], float4 (&v)[NVEC], float4* slab, int lane) {
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) slab[64 * i + lane] = t[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) v[i] = slab[NVEC * lane + i];
+    __builtin_amdgcn_wave_barrier();                     // the next exchange reuses the slab (a wave's LDS operations run in order)
+}
+
 // Reverse direction for stores: v (this lane's chunk) -> t (tile order).  Plain vector VALUES in and out: with float4
 // arrays by reference the result array stayed a stack object and went through scratch around the wave barrier
 // (64 bytes per lane in every D = 3 kernel that stores points).
@@ -320,13 +351,37 @@ __device__ __forceinline__ void for_each_chunk_ring(long N, bool vec, const floa
     }
     const long nchunks = N / PPT;
     if constexpr (D == 3) {
+        // whole waves: the tiles of ALL operands of two chunks are requested (coalesced) before the first of them goes
+        // through the wave's LDS slab; a form that fetched and exchanged operand by operand waited out every miss in
+        // turn (loss_grad, d = 3 order 2: 135 -> 231 us at 2^25 points)
+        __shared__ float4 slab3[BLOCK / 64][3 * 64];
+        const int lane = threadIdx.x & 63;
+        float4* slab = slab3[threadIdx.x >> 6];
         long c = tid;
         for (; c + nthreads < nchunks; c += 2 * nthreads) {
             float a[NA][PPT][D], b[NA][PPT][D];
+            if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {
+                float4 ta[NA][NV], tb[NA][NV], va[NV];
 #pragma unroll
-            for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c, a[q]);
+                for (int q = 0; q < NA; ++q) load_tile_raw<NV, true>(arr[q], c - lane, lane, ta[q]);
 #pragma unroll
-            for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c + nthreads, b[q]);
+                for (int q = 0; q < NA; ++q) load_tile_raw<NV, true>(arr[q], c + nthreads - lane, lane, tb[q]);
+#pragma unroll
+                for (int q = 0; q < NA; ++q) {
+                    exchange_tile<NV>(ta[q], va, slab, lane);
+                    unpack_chunk<D>(va, a[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < NA; ++q) {
+                    exchange_tile<NV>(tb[q], va, slab, lane);
+                    unpack_chunk<D>(va, b[q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c, a[q]);
+#pragma unroll
+                for (int q = 0; q < NA; ++q) load_chunk<D>(arr[q], c + nthreads, b[q]);
+            }
             compute(c, a);
             compute(c + nthreads, b);
         }

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
-from hypothesis import HealthCheck, given, settings
+from hypothesis import HealthCheck, assume, given, settings
 from hypothesis import strategies as st
 
 from oracle import sindy_oracle as O
@@ -174,6 +174,9 @@ def test_streaming_maps_and_euler_pair_random(eng, lib, sine, exp, n, K, off, se
         for _ in range(K):
             hh, jt = torch.autograd.functional.jvp(f3, xs, ts, create_graph=True)
             xs, ts = xs + dt * hh, ts + dt * jt
+        # exp columns can blow the K-step flow past the fp32 range (an example with |x_K| = 1.6e39 in fp64 turned up):
+        # nothing to compare there
+        assume(float(xs.detach().abs().max()) < 1e30 and float(ts.detach().abs().max()) < 1e30)
         ((xs * ga[off:].double()).sum() + (ts * ha[off:].double()).sum()).backward()
         xo, to = eng.euler_jvp(x, v, Xi.cuda(), mask.cuda(), order, fl, K, dt)
         assert close(xo, xs.detach(), 2e-5) and close(to, ts.detach(), 2e-5)
