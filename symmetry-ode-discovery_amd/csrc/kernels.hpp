@@ -758,7 +758,7 @@ struct JChunk {
 // MSE = true: the whole closure of the reversed-regulariser runs in ONE pass -- the residual r = h(x) - dx shares
 // Theta(x) and h(x) with the regulariser, x is read once (40 instead of 16 + 32 bytes per point at D = 2, n_g = 1):
 //   sums[0] = sum r^2, sums[1] = sum_g sum u^2,  grad = d( sums[0] + w_sym sums[1] ) / dXi  (both under the same 1/(N D)).
-template <class Lib, bool MSE, int RING = 2>
+template <class Lib, bool MSE, int RING = 2, int XI_SGPR_FROM = 32>
 __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                                 const float* __restrict__ gx,
                                                                 const float* __restrict__ jgx, int n_g, long N, bool vec,
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __r
     float w[D * P];
     // two libraries per point live here: Xi in SGPRs from d*p = 32 (3 waves/SIMD at order 5) -- and up to 80, the d = 3
     // order-3 libraries with sine / exp columns (69-78 coefficients would otherwise sit in VGPRs beside 70-79 sums)
-    load_xi<Lib, 32, 80>(xi, mask, s, w);
+    load_xi<Lib, XI_SGPR_FROM, 80>(xi, mask, s, w);
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;

@@ -87,9 +87,9 @@ int main(int argc, char** argv) {
     printf("# one problem, N = %ld points (d = 2)\n", N1);
     const int grids[] = {128, 256, 512, 768, 1024, 2048};
     for (int g : grids) {
-        double us = time_us([&] { loss_grad_kernel<L3, 7><<<dim3(g, 1), dim3(BLOCK)>>>(x, dx, N1, true, xi3, nullptr, part, fin, true); }, 10);
+        double us = time_us([&] { loss_grad_kernel<L3, true><<<dim3(g, 1), dim3(BLOCK)>>>(x, dx, N1, true, xi3, nullptr, part, fin, true); }, 10);
         printf("loss_grad o3 ring4 seg grid=%d: %.1f us %.0f GB/s\n", g, us, N1 * 16.0 / us * 1e-3);
-        us = time_us([&] { loss_grad_kernel<L5, 7><<<dim3(g, 1), dim3(BLOCK)>>>(x, dx, N1, true, xi5, nullptr, part, fin, true); }, 10);
+        us = time_us([&] { loss_grad_kernel<L5, true><<<dim3(g, 1), dim3(BLOCK)>>>(x, dx, N1, true, xi5, nullptr, part, fin, true); }, 10);
         printf("loss_grad o5 ring4 seg grid=%d: %.1f us %.0f GB/s\n", g, us, N1 * 16.0 / us * 1e-3);
     }
 #define REV1(LIB, MSEF, RG, BPP)                                                                                               \
@@ -119,8 +119,17 @@ int main(int argc, char** argv) {
     }
     REVB(2)
     REVB(3)
+    // Xi of the order-5 closure in VGPRs instead of SGPRs (42 more registers: 2 waves per SIMD instead of 3)
     for (int g : gxs) {
-        const double us = time_us([&] { loss_grad_kernel<L5, 7><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, NB, true, xi5, nullptr, part, fin, false); }, 5);
+        const double us = time_us([&] {
+            symreg_reversed_kernel<L5, true, 2, 1000><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, true, xi5, nullptr,
+                                                                                          0.1f, part, fin2);
+        }, 5);
+        printf("closure o5 batched ring=2 Xi in VGPRs grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", g, us, NT * 40.0 / us * 1e-3,
+               NT * 40.0 / us * 1e-3 / 8000);
+    }
+    for (int g : gxs) {
+        const double us = time_us([&] { loss_grad_kernel<L5, true><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, NB, true, xi5, nullptr, part, fin, false); }, 5);
         printf("loss_grad o5 batched ring4 grid.x=%d: %.1f us %.0f GB/s\n", g, us, NT * 16.0 / us * 1e-3);
     }
     CK(hipDeviceSynchronize());
