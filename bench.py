@@ -592,7 +592,7 @@ def main():
         "config": {"workload": f"damped_oscillator n_ics={a.n_ics} steps={a.n_steps} dim=2 poly-order={order} "
                                f"EquivSINDy-c (so2), {S} (trajectory,seed) problems per GPU resident in HBM; "
                                f"step = closure ({parts}"
-                               f"{', RCCL all-reduce of [loss|grad]' if (use_dist and a.shard == 'points') else ''})",
+                               f"{(', gloo (REHEARSAL on one GPU) all-reduce of [loss|grad]' if a.rehearse_gloo else ', RCCL all-reduce of [loss|grad]') if (use_dist and a.shard == 'points') else ''})",
                    "points_per_step_per_gpu": S * n_pts, "library_terms": clos.p, "sym_reg": a.sym_reg,
                    "parallelism": f"{a.shard[:-1]}-shard x{world}" if world > 1 else "single", "ranks_observed": ranks_observed},
         "roofline": {k: v for k, v in dominant.items() if k != "in_step"},
