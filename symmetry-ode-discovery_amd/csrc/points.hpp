@@ -43,35 +43,7 @@ struct Chunk {
 // A full wave instead fetches its 192-vector tile (256 points) coalesced -- lane l takes vectors l, 64+l, 128+l of the
 // tile -- and redistributes through a wave-private LDS slab: lane l reads back vectors 3l, 3l+1, 3l+2, its own chunk.
 // Preconditions (checked by the caller): all 64 lanes active, lane l holds chunk c0 + l.
-template <bool NT>
-__device__ __forceinline__ void load_tile3_raw(const float* __restrict__ a, long c0, int lane, float4 (&t)[3]) {
-    const float4* q = reinterpret_cast<const float4*>(a) + c0 * 3 + lane;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if constexpr (NT) {
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            const f4v u = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q + 64 * i));
-            t[i] = make_float4(u.x, u.y, u.z, u.w);
-        } else {
-            t[i] = q[64 * i];
-        }
-    }
-}
-
-// t (tile order) -> v (this lane's chunk) through slab[192]; the wave runs in lock step, so only the LDS counter
-// separates the writes from the reads (no workgroup barrier).
-__device__ __forceinline__ void exchange_tile3(const float4 (&t)[3], float4 (&v)[3], float4* slab, int lane) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) slab[64 * i + lane] = t[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // in front of the reads: behind them it sends v[] through scratch
-#pragma unroll
-    for (int i = 0; i < 3; ++i) v[i] = slab[3 * lane + i];
-    __builtin_amdgcn_wave_barrier();                     // the next exchange reuses the slab (a wave's LDS operations run in order)
-}
-
-// The same for any chunk of NVEC 16-byte vectors per lane (the regulariser's J_g at D = 3: 9 vectors = 144 bytes per lane,
+// Written for any chunk of NVEC 16-byte vectors per lane (the regulariser's J_g at D = 3: 9 vectors = 144 bytes per lane,
 // which as per-lane loads touch ~9x the lines they use and thrash the 32 KB L1 with 8-12 waves per CU): the wave fetches
 // its 64 NVEC-vector tile coalesced -- lane l takes vectors l, 64 + l, ... -- and reads its own chunk back from a
 // wave-private slab of 64 NVEC vectors.  ds_read_b128 at a lane stride of NVEC vectors is conflict-free for odd NVEC.
@@ -129,13 +101,13 @@ __device__ __forceinline__ void load_chunk(const float* __restrict__ a, long c, 
     typedef float f4v __attribute__((ext_vector_type(4)));
     float f[NV * 4];
     if constexpr (D == 3) {
-        // callers hand consecutive chunks to consecutive lanes (for_each_point): a whole wave takes the coalesced tile
+        // callers hand consecutive chunks to consecutive lanes (chunk c of lane l = base + l): a whole wave takes the coalesced tile
         if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {
             SYMODE_TILE3_SLAB(slab);
             const int lane = threadIdx.x & 63;
             float4 t[3], v[3];
-            load_tile3_raw<true>(a, c - lane, lane, t);
-            exchange_tile3(t, v, slab[threadIdx.x >> 6], lane);
+            load_tile_raw<3, true>(a, c - lane, lane, t);
+            exchange_tile<3>(t, v, slab[threadIdx.x >> 6], lane);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 f[4 * i + 0] = v[i].x;
@@ -245,31 +217,6 @@ template <int D>
 __device__ __forceinline__ void store_point(float* __restrict__ a, long n, const float (&p)[D]) {
 #pragma unroll
     for (int i = 0; i < D; ++i) a[n * D + i] = p[i];
-}
-
-// Visit every point of one (N, D) problem with the calling block's threads:
-//   vec == true : grid-stride over 16-byte chunks, then the < PPT leftover points;
-//   vec == false: grid-stride over single points (unaligned base or ragged row length).
-// `body(n, loader)` receives the point index and is expected to pull its operands through
-// the PointSource helpers below.
-template <int D, int BLOCK, typename ChunkBody, typename PointBody>
-__device__ __forceinline__ void for_each_point(long N, bool vec, ChunkBody chunk_body, PointBody point_body) {
-    constexpr int PPT = Chunk<D>::PPT;
-    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
-    const long nthreads = (long)gridDim.x * BLOCK;
-    if (vec) {
-        const long nchunks = N / PPT;
-        long c = tid;
-        for (; c + nthreads < nchunks; c += 2 * nthreads) {      // two independent chunks per step: more bytes in flight
-            chunk_body(c);
-            chunk_body(c + nthreads);
-        }
-        if (c < nchunks) chunk_body(c);
-        const long n = nchunks * PPT + tid;
-        if (n < N) point_body(n);
-    } else {
-        for (long n = tid; n < N; n += nthreads) point_body(n);
-    }
 }
 
 // Two-chunk software pipeline over one (N, D) problem: per step the operands of chunks c and c + nthreads are
