@@ -566,6 +566,30 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert c3["gram_kernel_us"] > 0 and c3["allreduce_us"] > 0 and c3["allreduced_vs_single_rank_max_rel_err"] < 1e-12
 
 
+def test_bench_collective_path_on_rccl_with_one_rank(tmp_path):
+    """RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so on this box the real backend can carry ONE rank
+    only: ``bench.py --force_dist`` initialises the "nccl" process group and sends the step's packed [loss | grad] buffers
+    and the config[3] Gram stack through RCCL's all-reduce on the kernels' stream -- the value must equal the
+    collective-free run's (an all-reduce over one rank is the identity) and the line must say the collective ran."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force_dist", "--problems", "64", "--steps", "3", "--warmup", "1",
+                          "--no_cpu_baseline", "--profile", "--config3", "--master_port", "29541"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["ranks_observed"] == 1 and rec["value"] > 0
+    c3 = rec["config3_gram_allreduce"]
+    assert "error" not in c3, c3
+    assert c3["allreduce_us"] is not None and c3["allreduce_us"] > 0 and "gloo" not in str(c3.get("allreduce_backend", ""))
+    assert c3["allreduced_vs_single_rank_max_rel_err"] == 0.0
+
+
 @pytest.mark.parametrize("d,order,fl,K,n", only_compiled([(2, 2, 2, 10, 20000), (2, 3, 0, 3, 4097), (3, 2, 0, 5, 3001), (1, 4, 1, 16, 1000),
                                                           (2, 5, 0, 20, 2500), (4, 2, 0, 4, 999)]))
 def test_euler_reverse_sweep_state_stack_equals_recompute(eng, d, order, fl, K, n):
