@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of single HIP entry points (interleaved A/B rounds in one process).
 
-    SYMODE_LOSS_GRAD_VARIANT=1 python tools/kbench.py --op loss_grad --S 1024 --N 125000 --order 5
+    python tools/kbench.py --op loss_grad --S 1024 --N 125000 --order 5
 """
 import argparse
 import os
@@ -168,7 +168,7 @@ def main():
             call()
         fn = g.replay
     mn, med = timeit(fn, a.reps)
-    print(f"{a.op} variant={os.environ.get('SYMODE_LOSS_GRAD_VARIANT', '0')} S={a.S} N={a.N} d={a.d} order={a.order} p={p}: "
+    print(f"{a.op} S={a.S} N={a.N} d={a.d} order={a.order} p={p}: "
           f"min {mn*1e3:.1f} us  med {med*1e3:.1f} us  {pts/mn/1e6:.1f} Gpts/s  {byt/mn/1e6:.0f} GB/s (alg. bytes)")
 
 
