@@ -299,11 +299,11 @@ def _sharded_trainer_worker(rank, world, port, out_dir, kind):
 
 
 def test_lbfgs_trainer_on_point_shards_with_relative_regulariser(tmp_path):
-    """train_SIGED_lbfgs(group=...) with sym_reg_type 'i' / 'f': two ranks, half of the batch each, against the one-process
+    """train_SIGED_lbfgs(group=...) with sym_reg_type 'i' / 'f' / 'r': two ranks, half of the batch each, against the one-process
     fit of the whole batch -- same masks after a thresholding event, coefficients to 1e-3 of their scale (60 iterations of
     un-line-searched L-BFGS with an L1 term amplify sums that differ in their last bits: measured 2e-4; the closure
     itself agrees to 1e-5, previous test)."""
-    for kind in ("i", "f"):
+    for kind in ("i", "f", "r"):               # r: a plain batch mean per group element, summed over the ranks with the residual
         mp.spawn(_sharded_trainer_worker, args=(2, _free_port(), str(tmp_path), kind), nprocs=2, join=True)
         mp.spawn(_sharded_trainer_worker, args=(1, _free_port(), str(tmp_path), kind), nprocs=1, join=True)
         a, b = [np.load(tmp_path / f"trainer_{kind}_2_{r}.npz") for r in range(2)]

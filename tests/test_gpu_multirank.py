@@ -15,6 +15,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from oracle import sindy_oracle as O
+
 pytestmark = pytest.mark.gpu
 
 
@@ -163,3 +165,60 @@ def test_config2_relative_regulariser_closure_two_ranks_equals_one_rank(tmp_path
         e_grad = np.abs(r0[f"{kind}_grad"] - grad).max() / np.abs(grad).max()
         print(f"config2 sym_reg_type {kind}, 2 ranks vs 1: mse {e_val[0]:.2e}, regulariser {e_val[1]:.2e}, gradient {e_grad:.2e}")
         assert e_val.max() <= 1e-5 and e_grad <= 1e-5, (kind, e_val, e_grad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# train_SIGED_lbfgs(group=...) on the DEFAULT path (device-resident trainer): the ranks' partial [loss | grad] are summed
+# between the closure launch and the optimiser launch of every inner iteration (device_lbfgs.DeviceTrainer._epoch_sharded).
+# ---------------------------------------------------------------------------------------------------------------------
+def _trainer_rank(rank, world, port, out_dir, kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.chdir(out_dir)
+    import torch.distributed as dist
+    import symode_amd
+    from oracle import sindy_oracle as O
+    from tests.helpers import load_fixture_autoencoder, load_fixture_generator
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"
+    xs, dxs = O.rk4_trajectories(O.rhs_dosc, O.ics_dosc(12, np.random.RandomState(5)), 0.02, 500)
+    x = torch.from_numpy(xs.reshape(-1, 2)).float().to(dev)
+    dx = torch.from_numpy(dxs.reshape(-1, 2)).float().to(dev)
+    n = x.shape[0]
+    cut = n // 2 + 10                                                   # uneven shards of whole chunks
+    lo, hi = (0, n) if world == 1 else ((0, cut) if rank == 0 else (cut, n))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f6_symreg.npz"))
+    ae = load_fixture_autoencoder(g, "tanh_learn", "Tanh", device=dev)
+    gen = load_fixture_generator(g, "tanh_learn", "(2,1,2)", device=dev)
+    for p in list(ae.parameters()) + list(gen.parameters()):
+        p.requires_grad = False
+    r = symode_amd.SINDyRegression(2, 3, False, False, threshold=0.05, device=dev)
+    r.Xi.data = (torch.randn(2, 10, generator=torch.Generator().manual_seed(1)) * 0.1).to(dev)
+    symode_amd.train.train_SIGED_lbfgs(
+        train_loader=[(x[lo:hi].contiguous(), dx[lo:hi].contiguous())], test_loader=[], num_epochs=60, device=dev, log_interval=10 ** 9,
+        save_interval=10 ** 9, save_dir=f"t{world}", autoencoder=ae, generator=gen, regressor=r, regressor_dst=None, use_latent=False,
+        distill_latent=False, lr_sindy=0.1, w_sindy_z=0.0, w_sindy_x=1.0, sindy_reg_type="l1", w_sindy_reg=0.0, sym_reg_type="r",
+        w_sym_reg=0.05 if kind == "r" else 0.0, st_freq=50, threshold=0.05, int_t=0.1, int_dt=0.01, print_eq=False,
+        group=dist.group.WORLD if world > 1 else None)
+    np.savez(os.path.join(out_dir, f"trainer_{kind}_{world}_{rank}.npz"), Xi=r.get_Xi().detach().cpu().numpy(), mask=r.mask.cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["plain", "r"])
+def test_device_trainer_on_two_point_shards_equals_one_rank(tmp_path, kind):
+    """dosc, order 3, 6 000 points, with and without the reversed regulariser (tiny fixture autoencoder): two ranks through the
+    HIP engine (uneven shards, gloo) recover the mask of the one-rank fit; coefficients within the optimiser's stopping ball."""
+    mp.spawn(_trainer_rank, args=(2, _free_port(), str(tmp_path), kind), nprocs=2, join=True)
+    mp.spawn(_trainer_rank, args=(1, _free_port(), str(tmp_path), kind), nprocs=1, join=True)
+    a, b = [np.load(tmp_path / f"trainer_{kind}_2_{r}.npz") for r in range(2)]
+    one = np.load(tmp_path / f"trainer_{kind}_1_0.npz")
+    assert np.array_equal(a["Xi"], b["Xi"]) and np.array_equal(a["mask"], b["mask"])          # replicated decisions
+    assert np.array_equal(a["mask"], one["mask"])
+    want = np.zeros((2, 10))
+    want[:, :6] = O.SINDY_TRUTH["dosc"] != 0
+    if kind == "plain":
+        assert np.array_equal(one["mask"] > 0, want > 0)                                       # the damped oscillator is recovered
+    assert np.abs(a["Xi"] - one["Xi"]).max() <= 1e-3 * np.abs(one["Xi"]).max()
