@@ -23,8 +23,14 @@ from .parser_utils import get_args
 from .sindy import SINDyRegression
 
 
-def main(argv=None):
+def main(argv=None, backend='nccl', one_gpu=False):
+    """``WORLD_SIZE`` > 1 (python -m torch.distributed.run --nproc-per-node N -m symode_amd.main ...): the L-BFGS fits shard
+    their fixed batch over the ranks' GPUs by points -- every rank draws the SAME batch (same seed) and keeps rows
+    [r m / W, (r+1) m / W); loss, gradient and, for the relative regularisers, numerators and denominators are summed over
+    the ranks inside ``train_SIGED_lbfgs(group=...)``; rank 0 alone prints and writes.  ``backend`` / ``one_gpu``: gloo
+    rehearsal with every rank on cuda:0 (tests)."""
     args = get_args(argv=argv)
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     T.wandb.init(project='anonym', entity='anonym', name=args.wandb_name, config=args)
     seed = args.seed
     torch.manual_seed(seed)
@@ -32,8 +38,36 @@ def main(argv=None):
     args = vars(args)
     if str(args['device']) == 'cpu':
         raise SystemExit('symode_amd runs the SINDy path on the GPU only (no CPU fallback): a HIP device is required')
+    group = None
+    if world > 1:
+        import contextlib
+        import io
+        import torch.distributed as dist
+        if args['mt_data'] or args['sindy_optimizer'] != 'lbfgs' or args['use_latent']:
+            raise SystemExit('multi-rank runs of symode_amd.main cover the non-latent L-BFGS fits (point shards)')
+        local = 0 if one_gpu else int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        args['device'] = torch.device('cuda', local)
+        if not dist.is_initialized():
+            dist.init_process_group(backend, **({'device_id': args['device']} if backend == 'nccl' else {}))
+        group = dist.group.WORLD
+        if rank != 0:                                       # one rank makes the data files and talks
+            dist.barrier()
+            with contextlib.redirect_stdout(io.StringIO()):
+                return _run(args, seed, group, rank, world)
+        train_dataset_first = get_dataset(args)             # (rank 0 writes ./data/*.pt if they are missing)
+        dist.barrier()
+        return _run(args, seed, group, rank, world, train_dataset_first)
+    return _run(args, seed, group, rank, world)
 
-    train_dataset, val_dataset, args = get_dataset(args)
+
+def _run(args, seed, group, rank, world, datasets=None):
+    train_dataset, val_dataset, args = datasets if datasets is not None else get_dataset(args)
+    if group is not None:
+        # rank 0 may just have GENERATED the data files (drawing random numbers) where the others read them: from here on
+        # every rank must draw the same batch and the same initial coefficients
+        torch.manual_seed(seed)
+        np.random.seed(seed)
     # DataLoader semantics (main.py:33-39), served from device-resident arrays: one gather per batch
     if args['sindy_optimizer'] != 'lbfgs':
         train_loader = make_loader(train_dataset, args['batch_size'], True, args['device'])
@@ -78,8 +112,16 @@ def main(argv=None):
         train_fn = T.train_SIGED_lbfgs
     else:
         train_fn = T.train_SIGED
+    if group is not None:
+        x, dx = next(iter(train_loader))                    # the fit's ONE fixed batch (train.py:626): identical on every rank
+        m = x.shape[0]
+        lo, hi = rank * m // world, (rank + 1) * m // world
+        train_loader = [(x[lo:hi].contiguous(), dx[lo:hi].contiguous())]
+        args = dict(args, group=group)
     train_fn(autoencoder=autoencoder, discriminator=discriminator, generator=generator, regressor=regressor,
              regressor_dst=regressor_dst, train_loader=train_loader, test_loader=val_loader, **args)
+    if rank != 0:
+        return regressor
 
     out = f'saved_models/{args["save_dir"]}'
     os.makedirs(out, exist_ok=True)

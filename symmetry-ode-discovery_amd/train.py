@@ -49,6 +49,9 @@ def _as_float(d):
 
 
 def _save(regressor, save_dir, name):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return                                              # sharded fits: every rank holds the same model, rank 0 writes it
     os.makedirs(f'saved_models/{save_dir}', exist_ok=True)
     torch.save(regressor.state_dict(), f'saved_models/{save_dir}/{name}')
 

@@ -222,3 +222,43 @@ def test_device_trainer_on_two_point_shards_equals_one_rank(tmp_path, kind):
     if kind == "plain":
         assert np.array_equal(one["mask"] > 0, want > 0)                                       # the damped oscillator is recovered
     assert np.abs(a["Xi"] - one["Xi"]).max() <= 1e-3 * np.abs(one["Xi"]).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the single-seed driver under several ranks: python -m torch.distributed.run --nproc-per-node N -m symode_amd.main ...
+# ---------------------------------------------------------------------------------------------------------------------
+def _main_rank(rank, world, port, cwd, argv):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.chdir(cwd)
+    import torch.distributed as dist
+    import symode_amd  # noqa: F401
+    from symode_amd import main as M
+    M.main(list(argv), backend="gloo", one_gpu=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_main_driver_two_ranks_equals_one_rank(tmp_path):
+    """`symode_amd.main` on dosc at 20 % noise (order 2, the shipped config's hyper-parameters) with the L-BFGS batch sharded over
+    two ranks: with the data files on disk both runs draw the same batch, rank 0 writes the reference's files, and they hold
+    the one-process run's mask and -- to summation order through the optimiser -- its coefficients."""
+    argv = COMMON + ["--task", "dosc", "--lbfgs_subsample", "0.5", "--lr_sindy", "0.1", "--poly_order", "2", "--st_freq", "50",
+                     "--threshold", "5e-2", "--num_epochs", "100", "--ae_arch", "none"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        from symode_amd import main as M
+        M.main(argv + ["--save_dir", "m0"])                  # makes ./data/*.pt (drawing random numbers on the way)
+        M.main(argv + ["--save_dir", "m1"])                  # data on disk: the batch every later run draws, one rank or two
+    finally:
+        os.chdir(cwd)
+    mp.spawn(_main_rank, args=(2, _free_port(), str(tmp_path), argv + ["--save_dir", "m2"]), nprocs=2, join=True)
+    one = np.load(tmp_path / "eval_results" / "m1" / "seed0.npz")
+    two = np.load(tmp_path / "eval_results" / "m2" / "seed0.npz")
+    assert np.array_equal(one["coefficients"] != 0, two["coefficients"] != 0)
+    assert np.allclose(one["coefficients"], two["coefficients"], rtol=1e-3, atol=1e-4)
+    assert bool(one["correct_form_all"]) == bool(two["correct_form_all"])
+    assert sorted(os.listdir(tmp_path / "saved_models" / "m2")) == sorted(os.listdir(tmp_path / "saved_models" / "m1"))
