@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <string>
 #include <vector>
 
 #include "kernels.hpp"
@@ -33,6 +35,80 @@ __global__ void fill(float* a, long n, unsigned seed, float scale) {
         h ^= h >> 13;
         a[i] = scale * ((float)(h & 0xffffff) / 8388608.0f - 1.0f);
     }
+}
+
+// The fused closure's memory side alone: the same four streams (x, dx, g(x) 8 B/point each, J_g 16 B/point), the same
+// 16-byte non-temporal chunk loads in the same two-slot ring on the same (grid.x, problems) launch -- and six adds per
+// chunk instead of ~880 vector instructions.  What this reaches is the HBM ceiling of the closure's access pattern.
+__global__ __launch_bounds__(BLOCK) void stream_only_kernel(const float* __restrict__ x, const float* __restrict__ dx,
+                                                            const float* __restrict__ gx, const float* __restrict__ jgx, long N,
+                                                            float* __restrict__ out) {
+    const long s = blockIdx.y;
+    const float* xs = x + s * N * 2;
+    const float* ys = dx + s * N * 2;
+    const float* gs = gx + s * N * 2;
+    const float* js = jgx + s * N * 4;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
+    float acc = 0.0f;
+    chunk_ring<2, 5>(
+        N / 2, tid, nthreads,
+        [&](long q, float4 (&slot)[5]) {
+            float4 a[1], b[1], c[1];
+            load_chunk_raw<2, true>(xs, q, a);
+            load_chunk_raw<2, true>(ys, q, b);
+            load_chunk_raw<2, true>(gs, q, c);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v* jq = reinterpret_cast<const f4v*>(js) + q * 2;
+            const f4v j0 = __builtin_nontemporal_load(jq), j1 = __builtin_nontemporal_load(jq + 1);
+            slot[0] = a[0];
+            slot[1] = b[0];
+            slot[2] = c[0];
+            slot[3] = make_float4(j0.x, j0.y, j0.z, j0.w);
+            slot[4] = make_float4(j1.x, j1.y, j1.z, j1.w);
+        },
+        [&](long, const float4 (&slot)[5]) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc += slot[i].x + slot[i].y + slot[i].z + slot[i].w;
+        });
+    if (acc == 123456.789f) out[s * gridDim.x + blockIdx.x] = acc;      // (never true: keeps the loads alive without a store stream)
+}
+
+// ... and the same bytes as ONE flat stream over all problems (they are contiguous): G long-lived workgroups, ring depth R,
+// SLAB = true: every workgroup walks its own contiguous slab instead of striding through the whole array.
+template <int R, bool SLAB>
+__global__ __launch_bounds__(BLOCK) void stream_flat_kernel(const float* __restrict__ x, const float* __restrict__ dx,
+                                                            const float* __restrict__ gx, const float* __restrict__ jgx, long NT_,
+                                                            float* __restrict__ out) {
+    const long nchunks_all = NT_ / 2;
+    long nchunks = nchunks_all, c0 = (long)blockIdx.x * BLOCK + threadIdx.x, stride = (long)gridDim.x * BLOCK;
+    if (SLAB) {
+        const long per = (nchunks_all + gridDim.x - 1) / gridDim.x, lo = (long)blockIdx.x * per;
+        nchunks = lo + per < nchunks_all ? lo + per : nchunks_all;
+        c0 = lo + threadIdx.x;
+        stride = BLOCK;
+    }
+    float acc = 0.0f;
+    chunk_ring<R, 5>(
+        nchunks, c0, stride,
+        [&](long q, float4 (&slot)[5]) {
+            float4 a[1], b[1], c[1];
+            load_chunk_raw<2, true>(x, q, a);
+            load_chunk_raw<2, true>(dx, q, b);
+            load_chunk_raw<2, true>(gx, q, c);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v* jq = reinterpret_cast<const f4v*>(jgx) + q * 2;
+            const f4v j0 = __builtin_nontemporal_load(jq), j1 = __builtin_nontemporal_load(jq + 1);
+            slot[0] = a[0];
+            slot[1] = b[0];
+            slot[2] = c[0];
+            slot[3] = make_float4(j0.x, j0.y, j0.z, j0.w);
+            slot[4] = make_float4(j1.x, j1.y, j1.z, j1.w);
+        },
+        [&](long, const float4 (&slot)[5]) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc += slot[i].x + slot[i].y + slot[i].z + slot[i].w;
+        });
+    if (acc == 123456.789f) out[blockIdx.x] = acc;
 }
 
 template <typename F>
@@ -84,6 +160,53 @@ int main(int argc, char** argv) {
     Finish fin2 = fin;
     fin2.n_loss = 2;
 
+    const bool walk_only = argc > 1 && std::string(argv[1]) == "walk";
+    {
+        // problem-walking closure: G workgroups, each a run of whole problems, one never-draining ring
+        printf("# walking closure, %ld problems x %ld points\n", S, NB);
+        std::vector<float> ref_l(2 * S), ref_g(S * D * L5::P), got_l(2 * S), got_g(S * D * L5::P);
+        symreg_reversed_kernel<L5, true, 2><<<dim3(2, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr, 0.1f,
+                                                                                  part, fin2);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ref_l.data(), loss, ref_l.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ref_g.data(), grad, ref_g.size() * 4, hipMemcpyDeviceToHost));
+        auto check = [&](const char* what) {
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(got_l.data(), loss, got_l.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(got_g.data(), grad, got_g.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (size_t i = 0; i < ref_l.size(); ++i) worst = std::max(worst, std::abs((double)got_l[i] - ref_l[i]) / (std::abs((double)ref_l[i]) + 1e-30));
+            double gs = 0;
+            for (size_t i = 0; i < ref_g.size(); ++i) gs = std::max(gs, std::abs((double)ref_g[i]));
+            for (size_t i = 0; i < ref_g.size(); ++i) worst = std::max(worst, std::abs((double)got_g[i] - ref_g[i]) / gs);
+            printf("   %s: worst relative difference to the (2, S) launch %.2e\n", what, worst);
+        };
+        const int wg[] = {768, 1024, 1536, 2048, 3072, 4096, 8192};
+#define WALKB(RG)                                                                                                                \
+        for (int g : wg) {                                                                                                       \
+            CK(hipMemset(loss, 0xff, 2 * S * 4));                                                                                \
+            CK(hipMemset(grad, 0xff, S * D * L5::P * 4));                                                                        \
+            const double us = time_us([&] {                                                                                      \
+                symreg_reversed_kernel<L5, true, RG, 32, true><<<dim3(g), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5,     \
+                                                                                        nullptr, 0.1f, part, fin2);               \
+            }, 5);                                                                                                               \
+            printf("closure o5 walking ring=%d workgroups=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", RG, g, us,                   \
+                   NT * 40.0 / us * 1e-3, NT * 40.0 / us * 1e-3 / 8000);                                                        \
+            if (g == 2048 || g == 768) check("walking");                                                                        \
+        }
+        WALKB(2)
+        WALKB(3)
+        WALKB(4)
+        for (int g : {1, 2, 4}) {
+            const double us = time_us([&] {
+                symreg_reversed_kernel<L5, true, 2><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr,
+                                                                                         0.1f, part, fin2);
+            }, 5);
+            printf("closure o5 (grid.x, S) ring=2 grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", g, us, NT * 40.0 / us * 1e-3,
+                   NT * 40.0 / us * 1e-3 / 8000);
+        }
+        if (walk_only) return 0;
+    }
     printf("# one problem, N = %ld points (d = 2)\n", N1);
     const int grids[] = {128, 256, 512, 768, 1024, 2048};
     for (int g : grids) {
@@ -95,7 +218,7 @@ int main(int argc, char** argv) {
 #define REV1(LIB, MSEF, RG, BPP)                                                                                               \
     for (int g : grids) {                                                                                                      \
         const double us = time_us([&] {                                                                                        \
-            symreg_reversed_kernel<LIB, MSEF, RG><<<dim3(g, 1), dim3(BLOCK)>>>(x, MSEF ? dx : nullptr, gx, jgx, 1, N1, true,    \
+            symreg_reversed_kernel<LIB, MSEF, RG><<<dim3(g, 1), dim3(BLOCK)>>>(x, MSEF ? dx : nullptr, gx, jgx, 1, N1, 1, true, \
                                                                                 (LIB::P == 10 ? xi3 : xi5), nullptr, 0.1f, part, \
                                                                                 MSEF ? fin2 : fin);                              \
         }, 10);                                                                                                                 \
@@ -111,7 +234,7 @@ int main(int argc, char** argv) {
 #define REVB(RG)                                                                                                                \
     for (int g : gxs) {                                                                                                         \
         const double us = time_us([&] {                                                                                         \
-            symreg_reversed_kernel<L5, true, RG><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, true, xi5, nullptr, \
+            symreg_reversed_kernel<L5, true, RG><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr, \
                                                                                        0.1f, part, fin2);                         \
         }, 5);                                                                                                                   \
         printf("closure o5 batched ring=%d grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", RG, g, us, NT * 40.0 / us * 1e-3,   \
@@ -122,11 +245,44 @@ int main(int argc, char** argv) {
     // Xi of the order-5 closure in VGPRs instead of SGPRs (42 more registers: 2 waves per SIMD instead of 3)
     for (int g : gxs) {
         const double us = time_us([&] {
-            symreg_reversed_kernel<L5, true, 2, 1000><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, true, xi5, nullptr,
+            symreg_reversed_kernel<L5, true, 2, 1000><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr,
                                                                                           0.1f, part, fin2);
         }, 5);
         printf("closure o5 batched ring=2 Xi in VGPRs grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", g, us, NT * 40.0 / us * 1e-3,
                NT * 40.0 / us * 1e-3 / 8000);
+    }
+    for (int g : gxs) {
+        const double us = time_us([&] { stream_only_kernel<<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, NB, loss); }, 5);
+        printf("the closure's four streams alone (ring=2, six adds per chunk) grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", g, us,
+               NT * 40.0 / us * 1e-3, NT * 40.0 / us * 1e-3 / 8000);
+    }
+    const int flat_grids[] = {256, 512, 768, 1024, 2048, 4096};
+#define FLAT(RR, SL)                                                                                                              \
+    for (int g : flat_grids) {                                                                                                    \
+        const double us = time_us([&] { stream_flat_kernel<RR, SL><<<dim3(g), dim3(BLOCK)>>>(x, dx, gx, jgx, NT, loss); }, 5);     \
+        printf("four streams, ONE flat pass, %s, ring=%d, %d workgroups: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n",                      \
+               SL ? "slab per workgroup" : "grid-stride", RR, g, us, NT * 40.0 / us * 1e-3, NT * 40.0 / us * 1e-3 / 8000);            \
+    }
+    FLAT(2, false)
+    FLAT(4, false)
+    FLAT(2, true)
+    FLAT(4, true)
+    // the same with the closure's residency: 52 KB of (unused) LDS per workgroup = 3 workgroups per CU = 3 waves per SIMD
+    {
+        const int grids2[] = {768, 1024, 4096, 8192, 16384};
+        CK(hipFuncSetAttribute((const void*)stream_flat_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 53248));
+        CK(hipFuncSetAttribute((const void*)stream_flat_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 53248));
+        for (int g : grids2) {
+            double us = time_us([&] { stream_flat_kernel<2, true><<<dim3(g), dim3(BLOCK), 53248>>>(x, dx, gx, jgx, NT, loss); }, 5);
+            printf("four streams, flat, slab, 3 waves/SIMD, ring=2, %d workgroups: %.1f us %.0f GB/s (%.3f)\n", g, us, NT * 40.0 / us * 1e-3,
+                   NT * 40.0 / us * 1e-3 / 8000);
+            us = time_us([&] { stream_flat_kernel<4, true><<<dim3(g), dim3(BLOCK), 53248>>>(x, dx, gx, jgx, NT, loss); }, 5);
+            printf("four streams, flat, slab, 3 waves/SIMD, ring=4, %d workgroups: %.1f us %.0f GB/s (%.3f)\n", g, us, NT * 40.0 / us * 1e-3,
+                   NT * 40.0 / us * 1e-3 / 8000);
+            us = time_us([&] { stream_flat_kernel<2, true><<<dim3(g), dim3(BLOCK)>>>(x, dx, gx, jgx, NT, loss); }, 5);
+            printf("four streams, flat, slab, 8 waves/SIMD, ring=2, %d workgroups: %.1f us %.0f GB/s (%.3f)\n", g, us, NT * 40.0 / us * 1e-3,
+                   NT * 40.0 / us * 1e-3 / 8000);
+        }
     }
     for (int g : gxs) {
         const double us = time_us([&] { loss_grad_kernel<L5, true><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, NB, true, xi5, nullptr, part, fin, false); }, 5);
