@@ -22,7 +22,7 @@ constexpr int MAP_CHUNKS_PER_THREAD = SYMODE_MAP_CHUNKS;   // chunks a thread of
 // for the tests and tuning tools that compare two settings inside one process; no launch path calls getenv.
 struct Knobs {
     long max_grid, min_grid_x, map_grid, gram_grid, gram_valu_grid, small_grid, reduce_grid;
-    int fused_finalize, euler_stack, gram_valu, gram_split, gram_valu_gather, segmented, row_split, walk_grid;
+    int fused_finalize, euler_stack, gram_valu, gram_split, gram_valu_gather, segmented, row_split;
 };
 
 inline Knobs read_knobs() {
@@ -43,7 +43,6 @@ inline Knobs read_knobs() {
     k.gram_valu_gather = on("SYMODE_GRAM_VALU_GATHER");
     k.segmented = (int)num("SYMODE_SEGMENTED", 1);
     k.row_split = (int)num("SYMODE_ROW_SPLIT", 1);
-    k.walk_grid = (int)num("SYMODE_WALK_GRID", 0);        // workgroups of the problem-walking closure launch; 0: off
     return k;
 }
 
@@ -759,27 +758,17 @@ struct JChunk {
 // MSE = true: the whole closure of the reversed-regulariser runs in ONE pass -- the residual r = h(x) - dx shares
 // Theta(x) and h(x) with the regulariser, x is read once (40 instead of 16 + 32 bytes per point at D = 2, n_g = 1):
 //   sums[0] = sum r^2, sums[1] = sum_g sum u^2,  grad = d( sums[0] + w_sym sums[1] ) / dXi  (both under the same 1/(N D)).
-//
-// WALK = true (many problems, D != 3, 16-byte streams, n_g > 0: the launcher checks): gridDim.x long-lived workgroups,
-// each walking a contiguous run of WHOLE problems with one register ring that never drains -- while the sums of a
-// finished problem go through the block reduction, the loads of the next problem's first chunks are already in flight.
-// One workgroup owns a problem, so it writes loss and gradient itself: no partial rows, no tickets, no finalisation.
-// (closure_ab, stream_flat: the closure's four streams alone reach 0.80 of 8 TB/s as 16384 short workgroups and 0.87 as
-//  1024-4096 slab-walking ones, whatever the occupancy.)
-template <class Lib, bool MSE, int RING = 2, int XI_SGPR_FROM = 32, bool WALK = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((WALK && Lib::D * Lib::P <= 44) ? 3 : 1))) void symreg_reversed_kernel(const float* __restrict__ x, const float* __restrict__ dx,
+template <class Lib, bool MSE, int RING = 2, int XI_SGPR_FROM = 32>
+__global__ __launch_bounds__(BLOCK) void symreg_reversed_kernel(const float* __restrict__ x, const float* __restrict__ dx,
                                                                 const float* __restrict__ gx,
-                                                                const float* __restrict__ jgx, int n_g, long N, long S, bool vec,
+                                                                const float* __restrict__ jgx, int n_g, long N, bool vec,
                                                                 const float* __restrict__ xi,
                                                                 const float* __restrict__ mask, float w_sym,
                                                                 double* __restrict__ ws, Finish fin) {
     vec = vec && chunked_stream<Lib>;            // (D = 3 sine / exp libraries: point by point, see chunked_stream)
     constexpr int D = Lib::D, P = Lib::P, NL = MSE ? 2 : 1, NACC = NL + D * P, PPT = Chunk<D>::PPT, NV = Chunk<D>::NV,
                   NVJ = JChunk<D>::NV, SYM0 = NL - 1;
-    long s = WALK ? (long)blockIdx.x * S / gridDim.x : (long)blockIdx.y;
-    if constexpr (WALK) {
-        if (s == (long)(blockIdx.x + 1) * S / gridDim.x) return;          // more workgroups than problems
-    }
+    const long s = blockIdx.y;
     const float* xs = x + s * N * D;
     const float* ys = MSE ? dx + s * N * D : nullptr;
     const float* gs = gx + s * (long)n_g * N * D;
@@ -887,8 +876,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((WALK && 
         });
     };
 
-    const long tid = WALK ? (long)threadIdx.x : (long)blockIdx.x * BLOCK + threadIdx.x,
-               nthreads = WALK ? (long)BLOCK : (long)gridDim.x * BLOCK;
+    const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
     // one chunk: its points' Theta(x), h(x) are formed once and live only while this chunk's group elements are visited
     auto chunk_all = [&](long c, const float4 (&vx)[NV], const float4 (&vy)[NV], const float4 (&vg)[NV], const float4 (&vj)[NVJ]) {
         if constexpr (D == 3) {
@@ -925,8 +913,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((WALK && 
             group(vg, vj, true);
             for (int g = 1; g < n_g; ++g) {
                 float4 ng[NV], nj[NVJ];
-                load_chunk_raw<D, true>(gx + (s * n_g + g) * N * D, c, ng);
-                load_j(jgx + (s * n_g + g) * N * D * D, c, nj);
+                load_chunk_raw<D, true>(gs + (long)g * N * D, c, ng);
+                load_j(js + (long)g * N * D * D, c, nj);
                 group(ng, nj, false);
             }
             return;
@@ -945,110 +933,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((WALK && 
         chunk_g(th, h, vg, vj, r);
         for (int g = 1; g < n_g; ++g) {
             float4 ng[NV], nj[NVJ];
-            load_chunk_raw<D, true>(gx + (s * n_g + g) * N * D, c, ng);
-            load_j(jgx + (s * n_g + g) * N * D * D, c, nj);
+            load_chunk_raw<D, true>(gs + (long)g * N * D, c, ng);
+            load_j(js + (long)g * N * D * D, c, nj);
             chunk_g(th, h, ng, nj, zero);
         }
     };
-    if constexpr (WALK && D != 3) {
-        constexpr int NVT = (MSE ? 3 : 2) * NV + NVJ, OY = NV, OG = (MSE ? 2 : 1) * NV, OJ = OG + NV;
-        __shared__ float lds[reduce_lds_floats(BLOCK)];
-        const long s_end = (long)(blockIdx.x + 1) * S / gridDim.x;                   // problems s .. s_end - 1 are this workgroup's
-        const int npl = (int)(s_end - s);
-        const unsigned nchunks = (unsigned)(N / PPT);
-        // rounds of a problem (BLOCK chunks each), padded to whole turns of the ring: the padding rounds re-read the last
-        // chunk (in bounds, unused), and every problem boundary falls between two turns
-        const unsigned CP = (nchunks + BLOCK * RING - 1) / (BLOCK * RING) * (BLOCK * RING);
-        // the loader runs one turn ahead of the consumer, with its own (uniform) cursor; past the last round it stays on it
-        long ls = s;                                      // the loader's problem
-        unsigned li = 0;
-        auto load = [&](float4 (&slot)[NVT]) __attribute__((always_inline)) {
-            unsigned q = li + threadIdx.x;
-            q = q < nchunks ? q : nchunks - 1;
-            const float *lx = x + ls * N * D, *ly = MSE ? dx + ls * N * D : nullptr, *lg = gx + ls * n_g * N * D,
-                        *lj = jgx + ls * n_g * N * D * D;
-            float4 tx[NV], tg[NV], tj[NVJ];
-            load_chunk_raw<D, true>(lx, q, tx);
-            load_chunk_raw<D, true>(lg, q, tg);
-            load_j(lj, q, tj);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                slot[i] = tx[i];
-                slot[OG + i] = tg[i];
-            }
-#pragma unroll
-            for (int i = 0; i < NVJ; ++i) slot[OJ + i] = tj[i];
-            if constexpr (MSE) {
-                float4 ty[NV];
-                load_chunk_raw<D, true>(ly, q, ty);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) slot[OY + i] = ty[i];
-            }
-            li += BLOCK;
-            if (li >= CP) {
-                if (ls + 1 < s_end) {
-                    li = 0;
-                    ++ls;
-                } else {
-                    li = CP - BLOCK;
-                }
-            }
-        };
-        // a finished problem: the sums of the 256 threads in fixed order, scaled and written (no ragged tail: problems that
-        // start on 16-byte boundaries hold whole chunks)
-        auto leave = [&]() __attribute__((always_inline)) {
-            block_reduce_emit_lds<NACC, BLOCK>(acc, lds, [&](int k, double v) {
-                if (k < NL) {
-                    if (fin.loss != nullptr) fin.loss[s * NL + k] = (float)(v * (double)fin.loss_scale);
-                } else {
-                    const long i = s * (D * P) + (k - NL);
-                    const float m = fin.mask ? fin.mask[i] : 1.0f;
-                    fin.grad[i] = (float)(v * (double)fin.grad_scale) * m;
-                }
-            });
-            __syncthreads();                              // the staging area is free for the next problem
-        };
-        auto enter = [&]() __attribute__((always_inline)) {
-            ++s;
-            load_xi<Lib, XI_SGPR_FROM, 80>(xi, mask, s, w);
-#pragma unroll
-            for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-        };
-        unsigned ui = 0;
-        auto use = [&](const float4 (&slot)[NVT]) __attribute__((always_inline)) {
-            const unsigned c = ui + threadIdx.x;
-            ui += BLOCK;
-            if (c < nchunks) {
-                float4 ax[NV], ay[NV], ag[NV], aj[NVJ];
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    ax[i] = slot[i];
-                    ay[i] = MSE ? slot[OY + i] : slot[i];
-                    ag[i] = slot[OG + i];
-                }
-#pragma unroll
-                for (int i = 0; i < NVJ; ++i) aj[i] = slot[OJ + i];
-                chunk_all(c, ax, ay, ag, aj);
-            }
-        };
-        float4 ring[RING][NVT];
-        each_point_static<0, RING>([&](auto k) { load(ring[k]); });
-        const unsigned turns = (unsigned)npl * (CP / (BLOCK * RING));
-        for (unsigned t = 0; t < turns; ++t) {
-            if (ui >= CP) {                               // between two turns: the next problem
-                leave();
-                enter();
-                ui = 0;
-            }
-            each_point_static<0, RING>([&](auto k) {
-                use(ring[k]);
-                load(ring[k]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        leave();
-        return;
-    } else if constexpr (D == 3) {
+    if constexpr (D == 3) {
         // 12-byte points and 36-byte Jacobians: whole waves fetch their tiles coalesced and redistribute through a
         // wave-private LDS slab (points.hpp, exchange_tile); ragged waves and the tail keep the per-lane loads
         if (vec && n_g > 0) {
@@ -1744,26 +1634,12 @@ hipError_t launch_symreg_reversed(const float* x, const float* dx, const float* 
     const bool multi = S > 1 || n_g > 1;
     const bool vec = ((uintptr_t)x % 16 == 0) && ((uintptr_t)gxp % 16 == 0) && ((uintptr_t)jgx % 16 == 0) &&
                      (!mse || (uintptr_t)dx % 16 == 0) && (!multi || ((n * D) % 4 == 0 && (n * D * D) % 4 == 0));
-    // many problems: a few thousand workgroups each walking a run of whole problems (see the kernel), else (gx, S)
-    if constexpr (D != 3) {
-        const int walk = knobs().walk_grid;
-        if (walk > 0 && vec && n_g > 0 && S >= 2L * walk && n / Chunk<D>::PPT >= BLOCK && chunked_stream<Lib>) {
-            if (mse)
-                symreg_reversed_kernel<Lib, true, 2, 32, true><<<dim3(walk), dim3(BLOCK), 0, st>>>(x, dx, gxp, jgx, n_g, n, S, vec, xi,
-                                                                                                 mask, w_sym, part, fin);
-            else
-                symreg_reversed_kernel<Lib, false, 2, 32, true><<<dim3(walk), dim3(BLOCK), 0, st>>>(x, nullptr, gxp, jgx, n_g, n, S, vec,
-                                                                                                  xi, mask, 1.0f, part, fin);
-            SYMODE_LAUNCH_CHECK();
-            return hipSuccess;
-        }
-    }
     if (mse)
-        symreg_reversed_kernel<Lib, true><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, gxp, jgx, n_g, n, S, vec, xi, mask,
-                                                                                       w_sym, part, fin);
+        symreg_reversed_kernel<Lib, true><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, dx, gxp, jgx, n_g, n, vec, xi, mask, w_sym,
+                                                                                       part, fin);
     else
-        symreg_reversed_kernel<Lib, false><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, nullptr, gxp, jgx, n_g, n, S, vec, xi,
-                                                                                        mask, 1.0f, part, fin);
+        symreg_reversed_kernel<Lib, false><<<dim3(gx, (unsigned)S), dim3(BLOCK), 0, st>>>(x, nullptr, gxp, jgx, n_g, n, vec, xi, mask,
+                                                                                        1.0f, part, fin);
     SYMODE_LAUNCH_CHECK();
     return launch_finalize(fin, part, S, gx, nacc, st);
 }

@@ -1,7 +1,8 @@
 // A/B harness for the closure kernels (tuning runs, not product code): loss_grad and the fused residual + reversed
 // regulariser closure straight from csrc/kernels.hpp, one big problem (S = 1, 2^26 points) and the bench's batched shape
 // (8192 x 125 000 points), over launch widths and ring depths -- one process, so variants see the same box.  (The run
-// kept as profiles/r03_closure_ab.txt also held the two-chunk form the ring replaced: ring=0 there.)
+// kept as profiles/r03_closure_ab.txt also held the two-chunk form the ring replaced: ring=0 there; the problem-walking
+// form of the closure measured in profiles/r03_closure_walk.txt lives in commit becc803 only.)
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -I symmetry-ode-discovery_amd/csrc
 //              -o tools/micro/closure_ab tools/micro/closure_ab.hip
 #include <hip/hip_runtime.h>
@@ -9,8 +10,6 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <cmath>
-#include <string>
 #include <vector>
 
 #include "kernels.hpp"
@@ -160,53 +159,6 @@ int main(int argc, char** argv) {
     Finish fin2 = fin;
     fin2.n_loss = 2;
 
-    const bool walk_only = argc > 1 && std::string(argv[1]) == "walk";
-    {
-        // problem-walking closure: G workgroups, each a run of whole problems, one never-draining ring
-        printf("# walking closure, %ld problems x %ld points\n", S, NB);
-        std::vector<float> ref_l(2 * S), ref_g(S * D * L5::P), got_l(2 * S), got_g(S * D * L5::P);
-        symreg_reversed_kernel<L5, true, 2><<<dim3(2, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr, 0.1f,
-                                                                                  part, fin2);
-        CK(hipDeviceSynchronize());
-        CK(hipMemcpy(ref_l.data(), loss, ref_l.size() * 4, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(ref_g.data(), grad, ref_g.size() * 4, hipMemcpyDeviceToHost));
-        auto check = [&](const char* what) {
-            CK(hipDeviceSynchronize());
-            CK(hipMemcpy(got_l.data(), loss, got_l.size() * 4, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(got_g.data(), grad, got_g.size() * 4, hipMemcpyDeviceToHost));
-            double worst = 0;
-            for (size_t i = 0; i < ref_l.size(); ++i) worst = std::max(worst, std::abs((double)got_l[i] - ref_l[i]) / (std::abs((double)ref_l[i]) + 1e-30));
-            double gs = 0;
-            for (size_t i = 0; i < ref_g.size(); ++i) gs = std::max(gs, std::abs((double)ref_g[i]));
-            for (size_t i = 0; i < ref_g.size(); ++i) worst = std::max(worst, std::abs((double)got_g[i] - ref_g[i]) / gs);
-            printf("   %s: worst relative difference to the (2, S) launch %.2e\n", what, worst);
-        };
-        const int wg[] = {768, 1024, 1536, 2048, 3072, 4096, 8192};
-#define WALKB(RG)                                                                                                                \
-        for (int g : wg) {                                                                                                       \
-            CK(hipMemset(loss, 0xff, 2 * S * 4));                                                                                \
-            CK(hipMemset(grad, 0xff, S * D * L5::P * 4));                                                                        \
-            const double us = time_us([&] {                                                                                      \
-                symreg_reversed_kernel<L5, true, RG, 32, true><<<dim3(g), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5,     \
-                                                                                        nullptr, 0.1f, part, fin2);               \
-            }, 5);                                                                                                               \
-            printf("closure o5 walking ring=%d workgroups=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", RG, g, us,                   \
-                   NT * 40.0 / us * 1e-3, NT * 40.0 / us * 1e-3 / 8000);                                                        \
-            if (g == 2048 || g == 768) check("walking");                                                                        \
-        }
-        WALKB(2)
-        WALKB(3)
-        WALKB(4)
-        for (int g : {1, 2, 4}) {
-            const double us = time_us([&] {
-                symreg_reversed_kernel<L5, true, 2><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr,
-                                                                                         0.1f, part, fin2);
-            }, 5);
-            printf("closure o5 (grid.x, S) ring=2 grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", g, us, NT * 40.0 / us * 1e-3,
-                   NT * 40.0 / us * 1e-3 / 8000);
-        }
-        if (walk_only) return 0;
-    }
     printf("# one problem, N = %ld points (d = 2)\n", N1);
     const int grids[] = {128, 256, 512, 768, 1024, 2048};
     for (int g : grids) {
@@ -218,7 +170,7 @@ int main(int argc, char** argv) {
 #define REV1(LIB, MSEF, RG, BPP)                                                                                               \
     for (int g : grids) {                                                                                                      \
         const double us = time_us([&] {                                                                                        \
-            symreg_reversed_kernel<LIB, MSEF, RG><<<dim3(g, 1), dim3(BLOCK)>>>(x, MSEF ? dx : nullptr, gx, jgx, 1, N1, 1, true, \
+            symreg_reversed_kernel<LIB, MSEF, RG><<<dim3(g, 1), dim3(BLOCK)>>>(x, MSEF ? dx : nullptr, gx, jgx, 1, N1, true,    \
                                                                                 (LIB::P == 10 ? xi3 : xi5), nullptr, 0.1f, part, \
                                                                                 MSEF ? fin2 : fin);                              \
         }, 10);                                                                                                                 \
@@ -234,7 +186,7 @@ int main(int argc, char** argv) {
 #define REVB(RG)                                                                                                                \
     for (int g : gxs) {                                                                                                         \
         const double us = time_us([&] {                                                                                         \
-            symreg_reversed_kernel<L5, true, RG><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr, \
+            symreg_reversed_kernel<L5, true, RG><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, true, xi5, nullptr, \
                                                                                        0.1f, part, fin2);                         \
         }, 5);                                                                                                                   \
         printf("closure o5 batched ring=%d grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", RG, g, us, NT * 40.0 / us * 1e-3,   \
@@ -245,7 +197,7 @@ int main(int argc, char** argv) {
     // Xi of the order-5 closure in VGPRs instead of SGPRs (42 more registers: 2 waves per SIMD instead of 3)
     for (int g : gxs) {
         const double us = time_us([&] {
-            symreg_reversed_kernel<L5, true, 2, 1000><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, S, true, xi5, nullptr,
+            symreg_reversed_kernel<L5, true, 2, 1000><<<dim3(g, (unsigned)S), dim3(BLOCK)>>>(x, dx, gx, jgx, 1, NB, true, xi5, nullptr,
                                                                                           0.1f, part, fin2);
         }, 5);
         printf("closure o5 batched ring=2 Xi in VGPRs grid.x=%d: %.1f us %.0f GB/s (%.3f of 8 TB/s)\n", g, us, NT * 40.0 / us * 1e-3,
