@@ -29,10 +29,12 @@ def _lbfgs(S, r, x, dx, lr, st_freq, thr, epochs, **kw):
                               st_freq=st_freq, threshold=thr, int_t=0.1, int_dt=0.01, print_eq=False, **kw)
 
 
-def test_config0_dosc_50x2500x2_order3_lbfgs(S, tmp_path, monkeypatch):
-    """configs[0]: damped oscillator n_ics=50 steps=2500 dim=2, plain SINDy with L-BFGS (lr 0.1, thr 5e-2, st_freq 50)."""
+@pytest.mark.parametrize("noise", [0.0, 0.05, 0.2])
+def test_config0_dosc_50x2500x2_order3_lbfgs(S, tmp_path, monkeypatch, noise):
+    """configs[0]: damped oscillator n_ics=50 steps=2500 dim=2, plain SINDy with L-BFGS (lr 0.1, thr 5e-2, st_freq 50);
+    noise-free and with 5 % / 20 % measurement noise on x (the reference's noisy operating points, run_configs/dosc/noise*)."""
     monkeypatch.chdir(tmp_path)
-    x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=0.0, seed=0, device=DEV)
+    x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=noise, seed=0, device=DEV)
     x, dx = x[0], dx[0]
     assert x.shape == (125000, 2)
     torch.manual_seed(0)
@@ -42,18 +44,22 @@ def test_config0_dosc_50x2500x2_order3_lbfgs(S, tmp_path, monkeypatch):
     _lbfgs(S, r, x, dx, 0.1, 50, 0.05, 60)
     reg = O.OracleRegressor(2, 3, threshold=0.05, Xi0=Xi0)
     O.lbfgs_fit(reg, x.cpu(), dx.cpu(), 60, 0.1, st_freq=50, threshold=0.05)
-    assert torch.equal(r.mask.cpu(), reg.mask)                                   # identical sparsity mask
+    assert torch.equal(r.mask.cpu(), reg.mask), r.near_threshold                 # identical sparsity mask
+    assert r.near_threshold == []                                                # no thresholding event was a close call
     want = (reg.Xi * reg.mask).detach().numpy()
     assert np.allclose((r.Xi * r.mask).detach().cpu().numpy(), want, rtol=1e-3, atol=2e-4)
     truth = np.zeros((2, 10))
     truth[:, :6] = O.SINDY_TRUTH["dosc"]
-    assert np.array_equal(r.mask.cpu().numpy() != 0, truth != 0)                 # and it is the true equation
+    if noise <= 0.05:
+        assert np.array_equal(r.mask.cpu().numpy() != 0, truth != 0)             # and it is the true equation
 
 
-def test_config1_dosc_order5_equivariant_so2(S, tmp_path, monkeypatch):
-    """configs[1]: same data, poly-order 5 (p = 21), EquivSINDy-c with L = so2 (lr 1.0, thr 1e-2, st_freq 100)."""
+@pytest.mark.parametrize("noise", [0.0, 0.05])
+def test_config1_dosc_order5_equivariant_so2(S, tmp_path, monkeypatch, noise):
+    """configs[1]: same data, poly-order 5 (p = 21), EquivSINDy-c with L = so2 (lr 1.0, thr 1e-2, st_freq 100);
+    noise-free and with 5 % measurement noise on x."""
     monkeypatch.chdir(tmp_path)
-    x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=0.0, seed=0, device=DEV)
+    x, dx = S.data.make_dataset("dosc", 50, 2500, dt=0.02, noise=noise, seed=0, device=DEV)
     x, dx = x[0], dx[0]
     so2 = torch.tensor([[0.0, 1.0], [-1.0, 0.0]])
     torch.manual_seed(1)
@@ -63,10 +69,11 @@ def test_config1_dosc_order5_equivariant_so2(S, tmp_path, monkeypatch):
     assert reg.use_kron_product == r.use_kron_product
     _lbfgs(S, r, x, dx, 1.0, 100, 0.01, 60)
     O.lbfgs_fit(reg, x.cpu(), dx.cpu(), 60, 1.0, st_freq=100, threshold=0.01)
-    assert torch.equal(r.mask.cpu(), reg.mask)
+    assert torch.equal(r.mask.cpu(), reg.mask), r.near_threshold
+    assert r.near_threshold == []
     got, want = (r.get_Xi() * r.mask).detach().cpu().numpy(), (reg.get_Xi() * reg.mask).detach().numpy()
     assert np.allclose(got, want, rtol=1e-3, atol=2e-4)
-    assert np.allclose(got[:, 1:3], [[-0.1, -1.0], [1.0, -0.1]], atol=2e-3)
+    assert np.allclose(got[:, 1:3], [[-0.1, -1.0], [1.0, -0.1]], atol=2e-3 if noise == 0 else 2e-2)
 
 
 def test_config1_closure_along_the_oracle_trajectory_full_size(S):
@@ -115,9 +122,11 @@ def test_config1_closure_along_the_oracle_trajectory_full_size(S):
     assert worst_l <= 1e-5 and worst_g <= 1e-5 and worst_o <= 1e-4, (worst_l, worst_g, worst_o)
 
 
-def test_config3_selkov_64_seed_sweep_full_size(S):
-    """configs[3]: selkov n_ics=10 x 10^4 steps, order 3, 64 seeds x 50 % subsamples, STLSQ (gamma 0, thr 7.5e-2)."""
-    x, dx = S.data.make_dataset("selkov", 10, 10000, dt=0.002, noise=0.0, seed=2, device=DEV)
+@pytest.mark.parametrize("noise", [0.0, 0.05])
+def test_config3_selkov_64_seed_sweep_full_size(S, noise):
+    """configs[3]: selkov n_ics=10 x 10^4 steps, order 3, 64 seeds x 50 % subsamples, STLSQ (gamma 0, thr 7.5e-2);
+    noise-free and with 5 % measurement noise on x."""
+    x, dx = S.data.make_dataset("selkov", 10, 10000, dt=0.002, noise=noise, seed=2, device=DEV)
     x, dx = x[0], dx[0]
     sw = S.sweep.SeedSweepSTLSQ(x, dx, 3, n_seeds=64, subsample=0.5, seed0=0)
     Xi, mask, passes = sw.solve(0.0, 0.075, lstsq_driver="gelsy")          # the oracle below is the CPU reference path
@@ -132,6 +141,8 @@ def test_config3_selkov_64_seed_sweep_full_size(S):
         assert np.allclose(Xi[s].numpy(), want, rtol=2e-4, atol=2e-4 * np.abs(want).max()), s
     # with the full-rank driver (what the reference computes on a GPU) every seed recovers the true equation
     Xi2, mask2, _ = sw.solve(0.0, 0.075, lstsq_driver="gels")
+    if noise > 0:
+        return
     assert all(np.array_equal(mask2[s].numpy() != 0, O.SINDY_TRUTH["selkov"] != 0) for s in range(64))
     assert np.allclose(Xi2.numpy(), np.broadcast_to(O.SINDY_TRUTH["selkov"], (64, 2, 10)), atol=2e-3)
     # the full-rank solve against an fp64 QR of the same rows on the final support: the Gram route (cond 9e3, squared in the
