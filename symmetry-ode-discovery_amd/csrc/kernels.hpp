@@ -152,6 +152,14 @@ inline int map_grid_for(long n, int pts_per_thread_iter) {
     return (int)g;
 }
 
+// Rounds (of BLOCK chunks) per workgroup of the forward map: a workgroup starts with D*P coefficient (and mask) loads and
+// products, which at order 4-5 cost as much issue time as two points of work.  2^26 points, d = 2, us at 1 / 4 rounds, same
+// box: order 4 208 / 172, order 5 209-216 / 169 (0.63 -> 0.79 of 8 TB/s); order 3 and the d = 3 libraries (coalesced-tile
+// loads) are best at 1.  forward_jvp (two more streams) moved by +-5 % either way over 1 / 2 / 4 rounds and coefficients
+// in VGPRs / SGPRs -- left at 1 (profiles/r03_map_rounds.txt).
+template <class Lib>
+constexpr int map_rounds = (Lib::D == 2 && Lib::D * Lib::P > 24) ? 4 : 1;
+
 inline bool vec_ok(const void* p, long n, int d, long S) {
     return ((uintptr_t)p % 16 == 0) && (S == 1 || (n * d) % 4 == 0);
 }
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void forward_kernel(const float* __restrict_
     struct Ops {
         float x[PPT][D];
     };
-    for_each_chunk2<D, BLOCK, Ops>(
+    for_each_chunk2<D, BLOCK, Ops, map_rounds<Lib>>(
         N, vec, [&](long c, Ops& o) { load_chunk<D>(x, c, o.x); },
         [&](long c, Ops& o) {
             float h[PPT][D];
@@ -1442,7 +1450,7 @@ hipError_t launch_theta(const float* x, long n, float* out, hipStream_t st) {
 template <class Lib>
 hipError_t launch_forward(const float* x, long n, const float* xi, const float* mask, float* out, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    const int g = map_grid_for(n, Chunk<Lib::D>::PPT);
+    const int g = map_grid_for(n, Chunk<Lib::D>::PPT * map_rounds<Lib>);
     const bool vec = vec_ok(x, n, Lib::D, 1) && vec_ok(out, n, Lib::D, 1);
     forward_kernel<Lib><<<dim3(g), dim3(BLOCK), 0, st>>>(x, n, vec, xi, mask, out);
     SYMODE_LAUNCH_CHECK();

@@ -219,29 +219,56 @@ __device__ __forceinline__ void store_point(float* __restrict__ a, long n, const
     for (int i = 0; i < D; ++i) a[n * D + i] = p[i];
 }
 
-// Two-chunk software pipeline over one (N, D) problem: per step the operands of chunks c and c + nthreads are
-// requested (load(c, ops): 16-byte non-temporal vectors through load_chunk) before either chunk is computed
-// (compute(c, ops)), so a lane keeps two chunks of every operand in flight; ragged tails and unaligned bases go
-// point by point.  Ops is the caller's bundle of per-chunk operand registers.
-template <int D, int BLOCK, class Ops, typename Load, typename Compute, typename PointBody>
+// Two-chunk software pipeline over one (N, D) problem: per step the operands of two chunks are requested (load(c, ops):
+// 16-byte non-temporal vectors through load_chunk) before either chunk is computed (compute(c, ops)), so a lane keeps
+// two chunks of every operand in flight; ragged tails and unaligned bases go point by point.  Ops is the caller's bundle
+// of per-chunk operand registers.
+//   ROUNDS = 1: chunks c and c + nthreads with a grid-wide stride (a map launches the whole index space as workgroups,
+//               so this is one chunk per lane);
+//   ROUNDS > 1: every workgroup owns contiguous slabs of ROUNDS * BLOCK chunks (chunks c and c + BLOCK per step): the
+//               launch still walks memory in address order, with ROUNDS chunks per lane -- for the order 4-5 libraries,
+//               whose 30-42 coefficient loads and mask products per workgroup cost as much issue time as two points of
+//               work (kernels.hpp, map_rounds).
+template <int D, int BLOCK, class Ops, int ROUNDS = 1, typename Load, typename Compute, typename PointBody>
 __device__ __forceinline__ void for_each_chunk2(long N, bool vec, Load load, Compute compute, PointBody point_body) {
     constexpr int PPT = Chunk<D>::PPT;
     const long tid = (long)blockIdx.x * BLOCK + threadIdx.x;
     const long nthreads = (long)gridDim.x * BLOCK;
     if (vec) {
         const long nchunks = N / PPT;
-        long c = tid;
-        for (; c + nthreads < nchunks; c += 2 * nthreads) {
-            Ops a, b;
-            load(c, a);
-            load(c + nthreads, b);
-            compute(c, a);
-            compute(c + nthreads, b);
-        }
-        if (c < nchunks) {
-            Ops a;
-            load(c, a);
-            compute(c, a);
+        if constexpr (ROUNDS == 1) {
+            long c = tid;
+            for (; c + nthreads < nchunks; c += 2 * nthreads) {
+                Ops a, b;
+                load(c, a);
+                load(c + nthreads, b);
+                compute(c, a);
+                compute(c + nthreads, b);
+            }
+            if (c < nchunks) {
+                Ops a;
+                load(c, a);
+                compute(c, a);
+            }
+        } else {
+            constexpr long PER = (long)ROUNDS * BLOCK;
+            for (long lo = (long)blockIdx.x * PER; lo < nchunks; lo += (long)gridDim.x * PER) {
+                const long hi = lo + PER < nchunks ? lo + PER : nchunks;
+                long c = lo + threadIdx.x;
+#pragma unroll 1                                          // (unrolled, forward_jvp keeps four chunks of operands live and loses occupancy)
+                for (; c + BLOCK < hi; c += 2 * BLOCK) {
+                    Ops a, b;
+                    load(c, a);
+                    load(c + BLOCK, b);
+                    compute(c, a);
+                    compute(c + BLOCK, b);
+                }
+                if (c < hi) {
+                    Ops a;
+                    load(c, a);
+                    compute(c, a);
+                }
+            }
         }
         const long n = nchunks * PPT + tid;
         if (n < N) point_body(n);

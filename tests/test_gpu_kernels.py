@@ -204,7 +204,7 @@ def test_odeint_golden(eng, golden, tag):
 
 
 @pytest.mark.parametrize("n", [1, 255, 256, 1027, 4096, 125000])
-@pytest.mark.parametrize("d,order,fl", only_compiled([(3, 3, 0), (3, 2, 3), (1, 4, 0), (2, 3, 0), (4, 2, 0)]))
+@pytest.mark.parametrize("d,order,fl", only_compiled([(3, 3, 0), (3, 2, 3), (1, 4, 0), (2, 3, 0), (4, 2, 0), (2, 5, 0), (2, 4, 0)]))
 def test_forward_and_odeint_chunked_streams_vs_oracle(eng, n, d, order, fl):
     """Streaming map kernels at ragged and full sizes for every chunk layout (d = 1: 4 points per 16 bytes, d = 2: 2, d = 3:
     coalesced 192-vector tiles redistributed through LDS for whole waves / strided loads for ragged ones, d = 4: 1)."""
@@ -219,6 +219,23 @@ def test_forward_and_odeint_chunked_streams_vs_oracle(eng, n, d, order, fl):
     want = O.odeint(f, x, 5 * 0.02 + 0.01, 0.02, "rk4")
     got = eng.odeint(x.cuda(), Xi.cuda(), mask.cuda(), order, fl, 5, 0.02, "rk4")
     assert np.allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("order", [3, 5])
+@pytest.mark.parametrize("cap", [None, 3])
+def test_forward_slabs_of_the_order_4_5_map_every_point_once(eng, order, cap):
+    """The forward map gives every workgroup contiguous slabs of four rounds of chunks at order 4-5 (kernels.hpp,
+    map_rounds) and one chunk per lane below: sizes around the slab boundaries (2048 points), a ragged last slab, and a
+    grid capped to 3 workgroups (SYMODE_MAP_GRID: every workgroup walks several slabs) -- each output row against fp64."""
+    torch.manual_seed(order)
+    p = O.term_count(2, order)
+    Xi, mask = (torch.randn(2, p) * 0.2).cuda(), (torch.rand(2, p) > 0.3).float().cuda()
+    with _env(**({} if cap is None else {"SYMODE_MAP_GRID": cap})):
+        for n in (2046, 2048, 2050, 4096 + 2, 3 * 2048 + 514, 100003):
+            x = (torch.randn(n, 2) * 0.3).clamp(-0.6, 0.6).cuda()
+            got = eng.forward(x, Xi, mask, order, 0).double().cpu()
+            want = O.theta(x.cpu(), order).double() @ (Xi * mask).double().cpu().T
+            assert_close_scaled(got.numpy(), want.numpy(), 2e-6, f"forward order={order} n={n} cap={cap}")
 
 
 @pytest.mark.parametrize("d,order,fl,method", only_compiled([(2, 3, 0, "rk4"), (2, 2, 2, "rk4"), (2, 5, 0, "euler"), (3, 2, 1, "rk4"), (1, 3, 0, "euler"), (4, 2, 0, "rk4")]))
