@@ -67,6 +67,19 @@ inline int gram_valu_grid(long n, long S, int d) {
     return (int)g;
 }
 
+// The 4x4-tile matrix-core Gram (gram_m4.hpp): a wave takes 64 points per pass and wants >= 8 passes to pay for its
+// epilogue (21 tiles across lanes and waves); ~1024 workgroups in all (3-4 resident per CU), its partials are 336 doubles.
+inline int gram_m4_grid(long n, long S) {
+    const long total = knobs().gram_m4_grid < 0 ? 1024 : (knobs().gram_m4_grid < 1 ? 1 : knobs().gram_m4_grid);
+    long g = (n + 256L * 8 - 1) / (256L * 8);
+    // one problem: exactly one resident round (3 workgroups per CU at 134 registers): 16 M points 286 us on 1024, where the
+    // last 256 workgroups run on a third of the chip
+    const long cap = S >= total / 2 ? 2 : (S == 1 && knobs().gram_m4_grid < 0 ? 768 : total / S);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 // One problem through a reduction kernel: the workgroups loop over the data with a grid-wide stride, so all of them read
 // one moving window of memory -- fewer, longer-lived workgroups keep that window (and the DRAM pages under it) tighter,
 // and the last workgroup has fewer partial rows to add.  The best count grows with the problem
@@ -97,7 +110,9 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
     if ((size_t)gram_grid(n, S) > g_red) g_red = (size_t)gram_grid(n, S);
     if ((size_t)gram_valu_grid(n, S, ops->d) + 8 > g_red) g_red = (size_t)gram_valu_grid(n, S, ops->d) + 8;   // (+8: the split form rounds up)
     const size_t a = (size_t)S * g_red * nacc;
-    const size_t b = (size_t)S * g_red * gram_partial;
+    size_t b = (size_t)S * g_red * gram_partial;
+    const size_t T4 = (size_t)(F + 3) / 4, m4 = (size_t)S * (size_t)gram_m4_grid(n, S) * (T4 * (T4 + 1) / 2 * 16);
+    if (m4 > b) b = m4;
     return (size_t)WS_HEADER_DOUBLES + (a > b ? a : b);      // [magic + tickets | partial rows]
 }
 
@@ -220,7 +235,7 @@ int symode_aug_gram(const float* x, const float* dx, long n_problems, long n, in
     if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, n);
     return (int)ops->aug_gram(x, dx, n_problems, n, nullptr, gram_out, (double*)workspace, gram_grid(n, n_problems),
-                              gram_valu_grid(n, n_problems, d), (hipStream_t)stream);
+                              gram_valu_grid(n, n_problems, d), gram_m4_grid(n, n_problems), (hipStream_t)stream);
 }
 
 int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const int* idx, long n_problems, long m, int d,
@@ -232,7 +247,7 @@ int symode_aug_gram_gather(const float* x, const float* dx, long n_src, const in
     if (misaligned(x, 4) || misaligned(dx, 4) || misaligned(idx, 4) || misaligned(gram_out, 8)) return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(n_problems, m);
     return (int)ops->aug_gram(x, dx, n_problems, m, idx, gram_out, (double*)workspace, gram_grid(m, n_problems),
-                              gram_valu_grid(m, n_problems, d), (hipStream_t)stream);
+                              gram_valu_grid(m, n_problems, d), gram_m4_grid(m, n_problems), (hipStream_t)stream);
 }
 
 int symode_symreg_linear(const float* z, long n, int d, int order, int flags, const float* xi, const float* mask,

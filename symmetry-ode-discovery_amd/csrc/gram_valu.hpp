@@ -14,6 +14,7 @@
 #include <utility>
 
 #include "gram.hpp"
+#include "gram_m4.hpp"
 
 namespace symode {
 
@@ -333,8 +334,9 @@ inline bool gram_valu_enabled() { return knobs().gram_valu != 0; }       // tuni
 
 template <class Lib>
 hipError_t launch_aug_gram_any(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
-                               int gx_mfma, int gx_valu, hipStream_t st) {
-    // (index-table launches of the 12 < F <= 24 libraries keep the MFMA form: the split kernel has no gather path)
+                               int gx_mfma, int gx_valu, int gx_m4, hipStream_t st) {
+    // (12 < F <= 24: the 4x4-tile matrix-core form for F >= 18 and for every index-table launch -- the split kernel has no
+    //  gather path --, the split vector-pipe form for contiguous rows at F < 18)
     if constexpr (GramValuShape<Lib>::OK) {
         if (gram_valu_enabled() && (idx == nullptr || gram_valu_gather_enabled())) {
             double* part = ws + WS_HEADER_DOUBLES;
@@ -345,6 +347,14 @@ hipError_t launch_aug_gram_any(const float* x, const float* dx, long S, long n, 
             SYMODE_LAUNCH_CHECK();
             return hipSuccess;
         }
+    }
+    if constexpr (GramM4Shape<Lib>::OK) {
+        // 4x4 tiles on the matrix cores: contiguous rows and index tables alike (gram_m4.hpp); SYMODE_GRAM_M4=0 keeps the
+        // split form / the 16x16 form below
+        // (batches of contiguous rows at F < 18 stay with the split form below -- F = 17 fills 64 % of its 15 tiles: 512 x
+        //  125 000 points 124 against 118 G points/s; one problem is faster here at every size: 16 M points 105 against 95)
+        if (knobs().gram_m4 != 0 && (idx != nullptr || S == 1 || GramM4Shape<Lib>::F >= 18 || !gram_split_enabled()))
+            return launch_aug_gram_m4<Lib>(x, dx, S, n, idx, gram, ws, gx_m4, st);
     }
     if constexpr (GramSplitShape<Lib>::OK) {
         if (gram_valu_enabled() && gram_split_enabled() && idx == nullptr) {

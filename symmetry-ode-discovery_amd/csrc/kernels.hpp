@@ -22,7 +22,8 @@ constexpr int MAP_CHUNKS_PER_THREAD = SYMODE_MAP_CHUNKS;   // chunks a thread of
 // for the tests and tuning tools that compare two settings inside one process; no launch path calls getenv.
 struct Knobs {
     long max_grid, min_grid_x, map_grid, gram_grid, gram_valu_grid, small_grid, reduce_grid;
-    int fused_finalize, euler_stack, gram_valu, gram_split, gram_valu_gather, segmented, row_split;
+    int fused_finalize, euler_stack, gram_valu, gram_split, gram_valu_gather, segmented, row_split, gram_m4;
+    long gram_m4_grid;
 };
 
 inline Knobs read_knobs() {
@@ -43,6 +44,8 @@ inline Knobs read_knobs() {
     k.gram_valu_gather = on("SYMODE_GRAM_VALU_GATHER");
     k.segmented = (int)num("SYMODE_SEGMENTED", 1);
     k.row_split = (int)num("SYMODE_ROW_SPLIT", 1);
+    k.gram_m4 = on("SYMODE_GRAM_M4");
+    k.gram_m4_grid = num("SYMODE_GRAM_M4_GRID", -1);
     return k;
 }
 
@@ -91,7 +94,7 @@ struct LibOps {
                                   const float* xi, const float* mask, float inv_count, float w_sym, float* loss, float* grad,
                                   double* ws, int gx, hipStream_t st);
     hipError_t (*aug_gram)(const float* x, const float* dx, long S, long n, const int* idx, double* gram, double* ws,
-                           int gx_mfma, int gx_valu, hipStream_t st);
+                           int gx_mfma, int gx_valu, int gx_m4, hipStream_t st);
     hipError_t (*vjp)(const float* x, const float* g, long n, const float* xi, const float* mask, float* grad_x,
                       float* grad_xi, double* ws, int gx, hipStream_t st);
     hipError_t (*forward_jvp)(const float* x, const float* v, long n, const float* xi, const float* mask, float* out,

@@ -663,30 +663,33 @@ def test_weak_gram_fused_contraction(eng, T, K, d, order, fl):
                                                         (3, 999, 3, 2, 0), (2, 1500, 4, 2, 0), (1, 70001, 3, 3, 0), (1, 8, 2, 5, 0)]
                                             if only_compiled([c[2:4]])])
 def test_gram_vector_pipe_and_matrix_core_forms_agree(eng, S, n, d, order, fl):
-    """Small libraries (F = p + d <= 12) take the fp64 vector-pipe Gram (one fma per distinct entry), 12 < F <= 24 its split
-    form (the triangle in 2, 3 or 4 runs over sibling workgroups: F = 13, 17, 19, 21, 23 here), larger ones and
-    SYMODE_GRAM_VALU=0 the fp64 MFMA form: all are fp64 sums of exact products -- equal to 1e-12, and to the host's."""
+    """Small libraries (F = p + d <= 12) take the fp64 vector-pipe Gram (one fma per distinct entry), 12 < F <= 24 the 4x4-tile
+    matrix-core form (gram_m4.hpp: F = 13, 17, 19, 21, 23 here; SYMODE_GRAM_M4=0: the split vector-pipe form, the triangle
+    in 2, 3 or 4 runs over sibling workgroups), larger ones and SYMODE_GRAM_VALU=0 the 16x16-tile MFMA form: all are fp64
+    sums of exact products -- equal to 1e-12, and to the host's."""
     torch.manual_seed(n)
     x, dx = (torch.randn(S, n, d) * 0.7).cuda(), torch.randn(S, n, d).cuda()
-    with _env(SYMODE_GRAM_VALU=1):
-        a = eng.aug_gram(x, dx, order, fl)
-    with _env(SYMODE_GRAM_VALU=0):
-        b = eng.aug_gram(x, dx, order, fl)
+    forms = [dict(SYMODE_GRAM_M4=1, SYMODE_GRAM_VALU=1), dict(SYMODE_GRAM_M4=0, SYMODE_GRAM_VALU=1), dict(SYMODE_GRAM_M4=0, SYMODE_GRAM_VALU=0)]
+    got = []
+    for env in forms:
+        with _env(**env):
+            got.append(eng.aug_gram(x, dx, order, fl))
     th = eng.theta(x.reshape(-1, d), order, fl).reshape(S, n, -1)
     A = torch.cat([th, dx], dim=2).double().cpu()
     want = A.transpose(1, 2) @ A
-    for g in (a, b):
+    for g in got:
         assert torch.allclose(g.cpu(), want, rtol=1e-12, atol=1e-12 * want.abs().max().item())
-    assert torch.equal(a, a.transpose(1, 2))
-    # the index-table form (seed sweeps) through both
+        assert torch.equal(g, g.transpose(1, 2))
+    # the index-table form (seed sweeps) through all of them
     idx = torch.stack([torch.randperm(n)[: n // 2] for _ in range(4)]).int().cuda()
-    with _env(SYMODE_GRAM_VALU=1):
-        ga = eng.aug_gram_gather(x[0], dx[0], idx, order, fl)
-    with _env(SYMODE_GRAM_VALU=0):
-        gb = eng.aug_gram_gather(x[0], dx[0], idx, order, fl)
-    assert torch.allclose(ga, gb, rtol=1e-12, atol=1e-12 * gb.abs().max().item())
+    gat = []
+    for env in forms:
+        with _env(**env):
+            gat.append(eng.aug_gram_gather(x[0], dx[0], idx, order, fl))
     Ai = A[0][idx[1].long().cpu()]
-    assert torch.allclose(ga[1].cpu(), Ai.T @ Ai, rtol=1e-12, atol=1e-12 * want.abs().max().item())
+    for g in gat:
+        assert torch.allclose(g, gat[-1], rtol=1e-12, atol=1e-12 * gat[-1].abs().max().item())
+        assert torch.allclose(g[1].cpu(), Ai.T @ Ai, rtol=1e-12, atol=1e-12 * want.abs().max().item())
 
 
 @pytest.mark.parametrize("S,n,n_g,d,order,fl", [(1, 20000, 1, 2, 2, 2), (3, 4096, 2, 2, 3, 0), (2, 125000, 1, 2, 5, 0), (1, 777, 3, 3, 2, 1), (2, 301, 1, 1, 4, 0)])
