@@ -6,7 +6,7 @@
     python tools/pmc_mfma.py <dir> aug_gram_kernel
 
 MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs): GRBM_GUI_ACTIVE is summed over the
-8 XCDs by rocprofv3 (MI355X_MICROARCH.md, DVFS section); BUSY_CYCLES counts cycles (64 per f64 16x16x4 MFMA).
+8 XCDs by rocprofv3 (MI355X_MICROARCH.md, DVFS section); BUSY_CYCLES counts cycles (64 per f64 16x16x4 MFMA, 16 per 4x4x4).
 """
 import csv
 import glob

@@ -31,7 +31,11 @@ export SYMODE_GRAM_VALU=0      # order 3 (F = 12) takes the vector-pipe Gram by 
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma3 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 3 --reps 3 > /dev/null 2>&1
 unset SYMODE_GRAM_VALU
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_gvalu -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 3 --reps 3 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_gvalu5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 3 > /dev/null 2>&1 && echo "gram pmc done"
+export SYMODE_GRAM_M4=0        # order 5 (F = 23) takes the 4x4-tile matrix-core Gram by default: this pass records the split vector-pipe form it replaced
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_gvalu5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 3 > /dev/null 2>&1
+unset SYMODE_GRAM_M4
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gram5 -- python3 "$R/tools/kbench.py" --op gram --S 1024 --N 125000 --order 5 --reps 5 > /dev/null 2>&1 && echo "gram pmc done"
 cd "$R"
 python tools/rocprof_summary.py /tmp/prof_bench > "$O/${TAG}_bench_kernel_stats.txt"
 python tools/rocprof_summary.py /tmp/prof_ops > "$O/${TAG}_ops_kernel_stats.txt"
@@ -44,6 +48,8 @@ python tools/rocprof_summary.py /tmp/prof_weak_big >> "$O/${TAG}_weak_gram_kerne
 python tools/pmc_mfma.py /tmp/pmc_mfma3 aug_gram_kernel > "$O/${TAG}_gram_o3_mfma_pmc.json"
 python tools/pmc_valu.py /tmp/pmc_gvalu aug_gram_valu_kernel > "$O/${TAG}_gram_o3_valu_pmc.json"
 python tools/pmc_valu.py /tmp/pmc_gvalu5 aug_gram_split_kernel > "$O/${TAG}_gram_o5_split_pmc.json"
+python tools/pmc_mfma.py /tmp/pmc_mfma5 aug_gram_m4_kernel > "$O/${TAG}_gram_o5_m4_mfma_pmc.json"
+python tools/rocprof_summary.py /tmp/prof_gram5 > "$O/${TAG}_gram_o5_kernel_stats.txt"
 python tools/latency_bench.py --orders 3 5 > "$O/${TAG}_latency.txt" 2>&1
 head -6 "$O/${TAG}_bench_kernel_stats.txt"
 cat "$O/pmc_traffic.json" | head -30
