@@ -374,11 +374,18 @@ def config3_leg(eng, dev, rank, world, group, gloo, reps=20):
         dist.all_reduce(counted, group=group)
         out["ranks_observed"] = int(round(counted.item()))
     # the whole sweep as main_sweep --method stlsq runs it: Gram launch + collective + 64 host threshold loops
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sw = SeedSweepSTLSQ(x_all, dx_all, order, n_seeds=S, group=group, engine=eng, idx=idx)
-    Xi, mask, passes = sw.solve(0.0, 0.075, max_iter=10)
-    out["sweep_wall_ms"] = (time.perf_counter() - t0) * 1e3
+    # (first call = first-touch costs of the process: reported apart; then the median of five)
+    walls = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        if group is not None:
+            dist.barrier(group=group)
+        t0 = time.perf_counter()
+        sw = SeedSweepSTLSQ(x_all, dx_all, order, n_seeds=S, group=group, engine=eng, idx=idx)
+        Xi, mask, passes = sw.solve(0.0, 0.075, max_iter=10)
+        walls.append((time.perf_counter() - t0) * 1e3)
+    out["sweep_wall_ms_first_call"] = walls[0]
+    out["sweep_wall_ms"] = sorted(walls[1:])[2]
     out["stlsq_passes"] = int(passes.sum())
     out["masks_sha"] = __import__("hashlib").sha256(mask.numpy().astype("uint8").tobytes()).hexdigest()[:16]
     if rank == 0:
