@@ -381,7 +381,7 @@ def config3_leg(eng, dev, rank, world, group, gloo, reps=20):
         if group is not None:
             dist.barrier(group=group)
         t0 = time.perf_counter()
-        sw = SeedSweepSTLSQ(x_all, dx_all, order, n_seeds=S, group=group, engine=eng, idx=idx)
+        sw = SeedSweepSTLSQ(x_all, dx_all, order, n_seeds=S, group=group, engine=eng, idx=idx, idx_sorted=True)
         Xi, mask, passes = sw.solve(0.0, 0.075, max_iter=10)
         walls.append((time.perf_counter() - t0) * 1e3)
     out["sweep_wall_ms_first_call"] = walls[0]

@@ -184,6 +184,14 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
 int symode_rk4_traj(const double* x0, long n_traj, int d, int order, int flags, const double* xi, int n_steps, double dt,
                     int subsample, float* x_out, float* dx_out, void* stream);
 
+/* Seed sweeps: idx_out (n_seeds, m) int32, rows ascending -- for every seed the m-subset of range(n) holding the m
+ * smallest of n counter-based keys key(seed, row): a seed's subsample depends on that seed alone (not on the other seeds,
+ * the world size or the device).  seeds: n_seeds int64 on the device.  One workgroup per seed (radix select + ordered
+ * compaction).  The table is what symode_aug_gram_gather takes.
+ * replaces: the first batch of DataLoader(train_dataset, batch_size=int(len * lbfgs_subsample), shuffle=True) of each
+ * seed's process, main.py:36-38 (there: torch's generator, one process per seed). */
+int symode_seeded_subsamples(long n, long m, const long long* seeds, int n_seeds, int* idx_out, void* stream);
+
 /* Fused K-step Euler flow f and its tangent map: x_out = f(x), t_out = J_f(x) v  for
  * f = n_steps explicit Euler steps of dx/dt = Theta(x)(xi*mask)^T (all steps in registers).
  * replaces: forward_step = odeint(regressor, ., int_t, int_dt) and jvp(forward_step, x, v_x)[1] of the

@@ -120,7 +120,7 @@ size_t workspace_doubles(const LibOps* ops, long S, long n) {
 
 extern "C" {
 
-int symode_abi_version(void) { return 4; }
+int symode_abi_version(void) { return 5; }
 
 void symode_reload_env(void) { knobs() = read_knobs(); }
 

@@ -1,0 +1,124 @@
+// Seeded subsamples of a data set for the seed sweeps: for every seed the m-subset of range(n) that holds the m smallest of
+// n keys key(seed, row) -- a counter-based hash, so a seed's subsample depends on that seed alone (not on the other seeds
+// of the sweep, the world size or the device), rows ascending.  One workgroup per seed: three radix-select passes over the
+// 32-bit keys (LDS histograms of 11 + 11 + 10 bits) find the m-th smallest key T and how many keys equal to T still
+// belong to the subset; one ordered compaction pass (wave ballots + one LDS scan of the 16 wave totals per 1024 rows)
+// writes the rows with key < T, and the first ties in row order.  Keys are recomputed in every pass (13 integer
+// instructions) instead of being stored.
+// replaces: the first batch of DataLoader(train_dataset, batch_size=int(len * lbfgs_subsample), shuffle=True) per seed
+// (main.py:36-38) as an index table; the torch form it replaced (one generator launch per seed, a batched top-k and a
+// sort) took 1.1-1.2 ms for 64 seeds of 10^5 rows, three quarters of the sequential-threshold sweep's wall time.
+#include <hip/hip_runtime.h>
+
+#include "../../include/symode.h"
+
+namespace {
+
+constexpr int SB = 1024;                                  // threads per workgroup: 16 waves
+
+__device__ __forceinline__ unsigned subsample_key(unsigned long long seed, unsigned long long row) {
+    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + row * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32);
+}
+
+__global__ __launch_bounds__(SB) void seeded_subsample_kernel(long n, long m, const long long* __restrict__ seeds,
+                                                              int* __restrict__ out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned wave_tot[2][SB / 64];
+    __shared__ unsigned sel_bin;
+    __shared__ long sel_need;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long seed = (unsigned long long)seeds[blockIdx.x];
+    int* dst = out + (long)blockIdx.x * m;
+
+    // radix select: after pass p the top bits of T are known (`prefix`), `need` = rank of T among the keys that share them
+    unsigned prefix = 0;
+    long need = m;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = shifts[pass], nb = 1 << widths[pass], hi = sh + widths[pass];
+        for (int b = tid; b < 2048; b += SB) hist[b] = 0;
+        __syncthreads();
+        for (long i = tid; i < n; i += SB) {
+            const unsigned k = subsample_key(seed, (unsigned long long)i);
+            if (hi >= 32 || (k >> hi) == (prefix >> hi)) atomicAdd(&hist[(k >> sh) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane l owns bins [l * per, (l + 1) * per): its total, the wave's exclusive prefix, then the bin that holds rank `need`
+            const int per = nb / 64;
+            unsigned mine = 0;
+            for (int j = 0; j < per; ++j) mine += hist[lane * per + j];
+            unsigned incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            unsigned long long cum = incl - mine;                        // keys in bins before this lane's
+            if ((long)cum < need && need <= (long)(cum + mine)) {        // exactly one lane
+                int b = lane * per;
+                while ((long)(cum + hist[b]) < need) {
+                    cum += hist[b];
+                    ++b;
+                }
+                sel_bin = (unsigned)b;
+                sel_need = need - (long)cum;
+            }
+        }
+        __syncthreads();
+        prefix |= sel_bin << sh;
+        need = sel_need;
+        __syncthreads();
+    }
+    const unsigned T = prefix;                                            // the m-th smallest key; `need` keys equal to T belong
+
+    // ordered compaction: 1024 rows per step, positions from wave ballots + a scan of the 16 wave totals
+    long base = 0, ties_before = 0;
+    for (long c0 = 0; c0 < n; c0 += SB) {
+        const long i = c0 + tid;
+        const unsigned k = i < n ? subsample_key(seed, (unsigned long long)i) : 0xFFFFFFFFu;
+        const bool in = i < n;
+        const bool eq = in && k == T;
+        const unsigned long long eq_mask = __ballot(eq);
+        if (lane == 0) wave_tot[0][wave] = (unsigned)__popcll(eq_mask);
+        __syncthreads();
+        long eq_before = ties_before;
+        unsigned eq_all = 0;
+        for (int w = 0; w < SB / 64; ++w) {
+            if (w < wave) eq_before += wave_tot[0][w];
+            eq_all += wave_tot[0][w];
+        }
+        eq_before += __popcll(eq_mask & ((1ull << lane) - 1ull));
+        const bool take = in && (k < T || (eq && eq_before < need));
+        const unsigned long long take_mask = __ballot(take);
+        if (lane == 0) wave_tot[1][wave] = (unsigned)__popcll(take_mask);
+        __syncthreads();
+        long pos = base;
+        unsigned take_all = 0;
+        for (int w = 0; w < SB / 64; ++w) {
+            if (w < wave) pos += wave_tot[1][w];
+            take_all += wave_tot[1][w];
+        }
+        pos += __popcll(take_mask & ((1ull << lane) - 1ull));
+        if (take) dst[pos] = (int)i;
+        base += take_all;
+        ties_before += eq_all;
+        __syncthreads();                                                  // wave_tot is rewritten by the next step
+    }
+}
+
+}  // namespace
+
+extern "C" int symode_seeded_subsamples(long n, long m, const long long* seeds, int n_seeds, int* idx_out, void* stream) {
+    if (n < 1 || n > 2147483647L || m < 1 || m > n || n_seeds < 1) return SYMODE_E_BADSIZE;
+    if (!seeds || !idx_out) return SYMODE_E_NULLPTR;
+    if (((uintptr_t)seeds % 8) != 0 || ((uintptr_t)idx_out % 4) != 0) return SYMODE_E_ALIGN;
+    seeded_subsample_kernel<<<dim3((unsigned)n_seeds), dim3(SB), 0, (hipStream_t)stream>>>(n, m, seeds, idx_out);
+    return (int)hipGetLastError();
+}

@@ -57,6 +57,7 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "symode_rk4_traj": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_int, ctypes.c_double, c_int, c_void_p, c_void_p,
                                 c_void_p]),
+    "symode_seeded_subsamples": (c_int, [c_long, c_long, c_void_p, c_int, c_void_p, c_void_p]),
     "symode_euler_jvp": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                  c_void_p, c_void_p]),
     "symode_euler_jvp_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -79,7 +80,7 @@ _SIGNATURES = {
     "symode_host_lstsq_normal": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, ctypes.c_double, c_void_p, c_void_p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class TrainerDesc(ctypes.Structure):
@@ -528,6 +529,15 @@ class HipEngine:
         self._check(self.lib.symode_rk4_traj(self._ptr(x0), n_traj, d, order, flags, self._ptr(xi), int(n_steps), float(dt),
                                              int(subsample), self._ptr(x), self._ptr(dx), self._stream(x0)), "symode_rk4_traj")
         return x, dx
+
+    def seeded_subsamples(self, n, m, seeds, device):
+        """(len(seeds), m) int32 index table, rows ascending: per seed the m rows of range(n) with the smallest counter-based
+        keys (symode_seeded_subsamples); depends on each seed alone."""
+        s = torch.as_tensor([int(v) for v in seeds], dtype=torch.int64).to(device)
+        out = torch.empty(len(s), int(m), dtype=torch.int32, device=s.device)
+        self._check(self.lib.symode_seeded_subsamples(int(n), int(m), self._ptr(s), len(s), self._ptr(out), self._stream(out)),
+                    "symode_seeded_subsamples")
+        return out
 
     def euler_jvp(self, x, v, xi, mask, order, flags, n_steps, dt):
         """(f(x), J_f(x) v) for f = n_steps Euler steps of the regressor ODE; one launch."""

@@ -111,7 +111,7 @@ def main(argv=None, engine=None, backend='nccl', one_gpu=False):
             raise SystemExit('--method stlsq sweeps the unconstrained library (use --method lbfgs for EquivSINDy-c)')
         idx = seeded_subsamples(n_all, m, seeds, dev)[:, lo:hi]
         sw = SeedSweepSTLSQ(x_all, dx_all, args['poly_order'], args['include_sine'], args['include_exp'], n_seeds=n_seeds,
-                            subsample=args['lbfgs_subsample'], seed0=args['seed'], group=group, engine=engine, idx=idx)
+                            subsample=args['lbfgs_subsample'], seed0=args['seed'], group=group, engine=engine, idx=idx, idx_sorted=True)
         Xi, mask, passes = sw.solve(args['w_sindy_reg'], args['threshold'], max_iter=max(1, args['num_epochs']),
                                     lstsq_driver=args.get('lstsq_driver'))
         if rank == 0:

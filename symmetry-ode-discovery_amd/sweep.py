@@ -21,27 +21,31 @@ from . import lstsq as _lstsq
 from .sindy import NEAR_THRESHOLD_BAND, near_threshold_cases, stlsq_solve_from_gram
 
 
-def seeded_subsamples(n, m, seeds, device):
-    """(len(seeds), m) int64, rows ascending: for every seed the m-subset of range(n) that holds the m smallest of n uniform
-    keys drawn from a generator seeded by THAT seed alone -- a seed's subsample (main.py:36-38: the first batch of a
-    shuffled loader) does not depend on which other seeds run beside it, nor on the world size (every rank draws the same
-    rows and takes its slice).  One key kernel per seed, ONE batched selection + sort for all of them: 1.1 ms for 64 seeds
-    of 10^5 rows, against 5 ms for a device randperm per seed and 0.5-1.1 s for torch's CPU randperm."""
+def seeded_subsamples(n, m, seeds, device, dtype=torch.int64):
+    """(len(seeds), m) index table, rows ascending: for every seed an m-subset of range(n) that depends on THAT seed alone -- a
+    seed's subsample (main.py:36-38: the first batch of a shuffled loader) does not depend on which other seeds run beside
+    it, nor on the world size (every rank draws the same rows and takes its slice).
+    On the GPU: ONE launch for all seeds (symode_seeded_subsamples: the m smallest of n counter-based keys per seed, radix
+    select + ordered compaction, a workgroup per seed) -- the torch form below (a generator launch per seed, one batched
+    top-k, one sort) took 1.1-1.2 ms for 64 seeds of 10^5 rows, three quarters of the STLSQ sweep.  On the CPU (tests of the
+    host logic): uniform keys from a torch generator seeded by the seed, the m smallest kept."""
     device = torch.device(device)
+    if m >= n:
+        return torch.arange(n, device=device, dtype=dtype).expand(len(seeds), n).contiguous()
+    if device.type == "cuda":
+        return get_engine().seeded_subsamples(n, m, seeds, device).to(dtype)
     g = torch.Generator(device=device)
     keys = torch.empty(len(seeds), n, dtype=torch.float64, device=device)          # fp64 keys: ties are not a concern
     for row, seed in zip(keys, seeds):
         g.manual_seed(int(seed))
         row.uniform_(generator=g)
-    if m >= n:
-        return torch.arange(n, device=device).expand(len(seeds), n).contiguous()
     idx = torch.topk(keys, m, dim=1, largest=False, sorted=False).indices
-    return torch.sort(idx, dim=1).values
+    return torch.sort(idx, dim=1).values.to(dtype)
 
 
 class SeedSweepSTLSQ:
     def __init__(self, x, dx, poly_order, include_sine=False, include_exp=False, n_seeds=64, subsample=0.5, seed0=0,
-                 group=None, engine=None, idx=None):
+                 group=None, engine=None, idx=None, idx_sorted=False):
         """x, dx: (N_local, d) rows of the flattened data set (dataset.py:193-194) this rank gathers from.
         ``idx`` (S, m_local) int32: the rows of x this rank contributes to each seed's subsample; by default every
         (seed, rank) draws its own seeded permutation of the rank's shard."""
@@ -59,13 +63,14 @@ class SeedSweepSTLSQ:
             self.m_local = idx.shape[1]
         # a seed's Gram is a sum over its rows: visit them in ascending order (near-sequential reads of x, dx)
         if idx is not None:
-            self.idx = torch.sort(self.idx, dim=1).values.contiguous()
+            if not idx_sorted:                               # (seeded_subsamples' tables already are)
+                self.idx = torch.sort(self.idx, dim=1).values.contiguous()
         else:
             rank = dist.get_rank(group) if group is not None else 0
             m = max(1, int(self.n_local * subsample))
             # seeded subset per (seed, rank): reproducible
             self.idx = seeded_subsamples(self.n_local, m, [1_000_003 * (seed0 + s) + rank for s in range(n_seeds)],
-                                         x.device).to(torch.int32)
+                                         x.device, dtype=torch.int32)
             self.m_local = m
         self._gram = None
 

@@ -819,3 +819,46 @@ def test_single_problem_launch_size_classes_vs_fp64(eng, n):
     l1, gr1 = eng.symreg_linear(x, Xi, None, L, order)
     assert np.isclose(l1.item(), s1.item(), rtol=2e-5)
     assert_close_scaled(gr1.cpu().numpy(), g1.cpu().numpy(), 2e-5, "symreg_linear")
+
+
+# ------------------------------------------------------------------------ seeded subsamples (seed sweeps)
+def _subsample_keys(seed, n):
+    """numpy restatement of subsample.hip::subsample_key (uint64 arithmetic wraps)"""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.arange(n, dtype=np.uint64) * np.uint64(0xD1B54A32D192ED03)
+             + np.uint64(0x632BE59BD9B4E019))
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return (z >> np.uint64(32)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (1000, 1), (1000, 999), (1024, 512), (1025, 3), (100000, 50000), (300001, 123457)])
+def test_seeded_subsamples_are_the_m_smallest_keys_in_row_order(eng, n, m):
+    """symode_seeded_subsamples: per seed the m rows with the smallest key(seed, row) (ties: the lower rows), ascending;
+    a seed's rows do not depend on the seeds beside it."""
+    seeds = [0, 1, 7, 1_000_003 * 5 + 2, 2 ** 40 + 17]
+    got = eng.seeded_subsamples(n, m, seeds, "cuda").cpu().numpy()
+    assert got.shape == (len(seeds), m) and got.dtype == np.int32
+    for row, seed in zip(got, seeds):
+        keys = _subsample_keys(seed, n)
+        want = np.sort(np.argsort(keys, kind="stable")[:m])
+        assert np.array_equal(row, want), (seed, n, m)
+    alone = eng.seeded_subsamples(n, m, [seeds[3]], "cuda").cpu().numpy()
+    assert np.array_equal(alone[0], got[3])
+
+
+def test_seeded_subsamples_ties_and_inclusion_rate(eng):
+    """2^22 rows have ~2000 pairs of equal 32-bit keys: the subset is still exactly m rows, and every row is in about half
+    of 64 seeds' half-size subsets."""
+    n, m = 1 << 22, 1 << 21
+    got = eng.seeded_subsamples(n, m, [3], "cuda").cpu().numpy()[0]
+    keys = _subsample_keys(3, n)
+    assert len(np.unique(keys)) < n                                           # there ARE ties in this table
+    assert np.array_equal(got, np.sort(np.argsort(keys, kind="stable")[:m]))
+    tab = eng.seeded_subsamples(20000, 10000, list(range(64)), "cuda")
+    counts = torch.zeros(20000, device="cuda").index_add_(0, tab.reshape(-1).long(), torch.ones(tab.numel(), device="cuda"))
+    assert abs(counts.mean().item() - 32.0) < 1e-6 and 10 < counts.min().item() and counts.max().item() < 54
+    assert abs(counts.std().item() - 4.0) < 0.3                              # binomial(64, 1/2)
