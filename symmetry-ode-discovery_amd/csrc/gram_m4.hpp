@@ -40,7 +40,8 @@ struct GramM4Shape {
     static constexpr int NT = T * (T + 1) / 2;           // lower-triangular tile pairs (ti >= tj), p = ti (ti + 1) / 2 + tj
     static constexpr int PARTIAL = NT * 16;              // doubles per workgroup partial
     // F <= 12 stays on the vector pipe (gram_valu.hpp): measured with this kernel, order 3 (F = 12, 6 tiles, 81 % useful):
-    // 2^26 points 317 against 275 us, 1024 x 125 000 574 against 514 us; only small launches gain (64 x 50 000: 22 against 25 us)
+    // 2^26 points 317 against 275 us, 1024 x 125 000 574 against 514 us; small launches gain a little (64 x 50 000: 22 against
+    // 25 us; config[3]'s index table 60 against 66 us), sparse index tables lose (64 x 62 500 of 8 M rows: 115 against 93 us)
     static constexpr bool OK = F > 12 && F <= 24;
 };
 
@@ -69,67 +70,92 @@ __global__ __launch_bounds__(BLOCK) void aug_gram_m4_kernel(const float* __restr
     for (int f = F; f < 4 * T; ++f) my[f * PS + lane] = 0.0f;                    // padding rows stay zero
 
     const long npass = (N + WAVE - 1) / WAVE;
-    // R passes of (x, dx) in flight per lane: a pass is 84 MFMAs (~0.6 us)
-    chunk_ring<R, NV>(
-        npass, (long)blockIdx.x * NW + wave, (long)gridDim.x * NW,
-        [&](long pass, float4 (&slot)[NV]) {
-            long n = pass * WAVE + lane;
-            n = n < N ? n : N - 1;                                               // ragged last pass: in bounds, zeroed below
-            const long src = is ? (long)is[n] : n;
-            float v[NV * 4];
+    // R passes of (x, dx) in flight per lane (a pass is 84 MFMAs, ~0.6 us, at F = 23), and for index-table launches the
+    // row indices one turn further ahead: the refill of a slot uses the index requested when the slot was filled last, so
+    // no load waits for the load before it (as one dependent chain per refill, the 64 x 50 000-row table of config[3]
+    // ran latency-bound)
+    auto src_of = [&](long pass) -> long {
+        pass = pass < npass ? pass : npass - 1;
+        long n = pass * WAVE + lane;
+        n = n < N ? n : N - 1;                                                   // ragged last pass: in bounds, zeroed below
+        return is ? (long)is[n] : n;
+    };
+    auto fetch = [&](long src, float4 (&slot)[NV]) __attribute__((always_inline)) {
+        float v[NV * 4];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                v[j] = xs[src * D + j];
-                v[D + j] = ys[src * D + j];
+        for (int j = 0; j < D; ++j) {
+            v[j] = xs[src * D + j];
+            v[D + j] = ys[src * D + j];
+        }
+#pragma unroll
+        for (int j = 2 * D; j < NV * 4; ++j) v[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) slot[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    };
+    auto use = [&](long pass, const float4 (&slot)[NV]) __attribute__((always_inline)) {
+        float v[NV * 4], xp[D], th[P];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[4 * i] = slot[i].x;
+            v[4 * i + 1] = slot[i].y;
+            v[4 * i + 2] = slot[i].z;
+            v[4 * i + 3] = slot[i].w;
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) xp[j] = v[j];
+        Lib::eval(xp, th);
+        if (pass * WAVE + WAVE <= N) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) my[j * PS + lane] = th[j];
+#pragma unroll
+            for (int j = 0; j < D; ++j) my[(P + j) * PS + lane] = v[D + j];
+        } else {
+            const bool live = pass * WAVE + lane < N;
+#pragma unroll
+            for (int j = 0; j < P; ++j) my[j * PS + lane] = live ? th[j] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) my[(P + j) * PS + lane] = live ? v[D + j] : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double g[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) g[t] = (double)rd[4 * t * PS + 2 * r];
+            int p = 0;
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj) {
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(g[ti], g[tj], acc[p], 0, 0, 0);
+                    ++p;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();                                         // the next pass overwrites the image (a wave's LDS operations run in order)
+    };
+    {
+        const long stride = (long)gridDim.x * NW;
+        long c = (long)blockIdx.x * NW + wave;
+        if (c < npass) {
+            float4 ring[R][NV];
+            long nxt[R];
+            each_point_static<0, R>([&](auto k) { fetch(src_of(c + k * stride), ring[k]); });
+            each_point_static<0, R>([&](auto k) { nxt[k] = src_of(c + (R + k) * stride); });
+            for (; c + (R - 1) * stride < npass; c += R * stride) {
+                each_point_static<0, R>([&](auto k) {
+                    use(c + k * stride, ring[k]);
+                    fetch(nxt[k], ring[k]);
+                    nxt[k] = src_of(c + (2 * R + k) * stride);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             }
-#pragma unroll
-            for (int j = 2 * D; j < NV * 4; ++j) v[j] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) slot[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-        },
-        [&](long pass, const float4 (&slot)[NV]) {
-            float v[NV * 4], xp[D], th[P];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                v[4 * i] = slot[i].x;
-                v[4 * i + 1] = slot[i].y;
-                v[4 * i + 2] = slot[i].z;
-                v[4 * i + 3] = slot[i].w;
-            }
-#pragma unroll
-            for (int j = 0; j < D; ++j) xp[j] = v[j];
-            Lib::eval(xp, th);
-            if (pass * WAVE + WAVE <= N) {
-#pragma unroll
-                for (int j = 0; j < P; ++j) my[j * PS + lane] = th[j];
-#pragma unroll
-                for (int j = 0; j < D; ++j) my[(P + j) * PS + lane] = v[D + j];
-            } else {
-                const bool live = pass * WAVE + lane < N;
-#pragma unroll
-                for (int j = 0; j < P; ++j) my[j * PS + lane] = live ? th[j] : 0.0f;
-#pragma unroll
-                for (int j = 0; j < D; ++j) my[(P + j) * PS + lane] = live ? v[D + j] : 0.0f;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double g[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) g[t] = (double)rd[4 * t * PS + 2 * r];
-                int p = 0;
-#pragma unroll
-                for (int ti = 0; ti < T; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj <= ti; ++tj) {
-                        acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(g[ti], g[tj], acc[p], 0, 0, 0);
-                        ++p;
-                    }
-            }
-            __builtin_amdgcn_wave_barrier();                                     // the next pass overwrites the image (a wave's LDS operations run in order)
-        });
+            each_point_static<0, R>([&](auto k) {
+                if (c + k * stride < npass) use(c + k * stride, ring[k]);
+            });
+        }
+    }
 
     // the four blocks of the instruction worked on different points: lanes l, l ^ 4, l ^ 8, l ^ 12 hold the same tile element
     __syncthreads();
