@@ -862,3 +862,26 @@ def test_seeded_subsamples_ties_and_inclusion_rate(eng):
     counts = torch.zeros(20000, device="cuda").index_add_(0, tab.reshape(-1).long(), torch.ones(tab.numel(), device="cuda"))
     assert abs(counts.mean().item() - 32.0) < 1e-6 and 10 < counts.min().item() and counts.max().item() < 54
     assert abs(counts.std().item() - 4.0) < 0.3                              # binomial(64, 1/2)
+
+
+def test_index_table_is_checked_once_per_table_and_again_after_a_change(eng):
+    """aug_gram_gather trusts a table it has checked (the check is a reduction + a sync, dearer than the kernel at config[3]'s
+    size) -- by tensor object and in-place version: an out-of-range row is refused on the first call, and a table spoiled in
+    place AFTER a good call is refused as well."""
+    import symode_amd
+    x, dx = torch.randn(1000, 2).cuda(), torch.randn(1000, 2).cuda()
+    idx = torch.arange(0, 1000, 2, dtype=torch.int32).repeat(3, 1).cuda()
+    bad = idx.clone()
+    bad[1, 7] = 1000
+    with pytest.raises(symode_amd.engine.SymodeError):
+        eng.aug_gram_gather(x, dx, bad, 3)
+    a = eng.aug_gram_gather(x, dx, idx, 3)
+    b = eng.aug_gram_gather(x, dx, idx, 3)                       # the remembered table
+    assert torch.equal(a, b)
+    idx[2, 0] = -1
+    with pytest.raises(symode_amd.engine.SymodeError):
+        eng.aug_gram_gather(x, dx, idx, 3)
+    other = torch.arange(1, 1000, 2, dtype=torch.int32).repeat(3, 1).cuda()
+    c = eng.aug_gram_gather(x, dx, other, 3)
+    A = torch.cat([eng.theta(x[1::2], 3), dx[1::2]], dim=1).double()
+    assert torch.allclose(c[0], A.T @ A, rtol=1e-12, atol=0)

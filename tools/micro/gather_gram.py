@@ -2,7 +2,7 @@
 MFMA form (default) vs the vector-pipe form (SYMODE_GRAM_VALU_GATHER=1; engine.reload_env() after every change)."""
 import os, sys
 import torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import symode_amd
 eng = symode_amd.get_engine()
 
