@@ -258,7 +258,8 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(const float* __restrict__ 
                 const int f = (int)(4 * v + i);
                 e[i] = tile[(f / P) * PS + (f % P)];
             }
-            reinterpret_cast<float4*>(dst)[v] = make_float4(e[0], e[1], e[2], e[3]);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f4v{e[0], e[1], e[2], e[3]}, reinterpret_cast<f4v*>(dst) + v);     // written once, never read here
         }
         for (long f = 4 * nvec + tid; f < total; f += BLOCK) dst[f] = tile[(int)(f / P) * PS + (int)(f % P)];
         __syncthreads();
