@@ -72,6 +72,16 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.symode_workspace_bytes(9, 3, 0, 1, 125000) == 0
 
 
+def test_argument_validation_of_the_seed_table_entry(lib):
+    null, junk = ctypes.c_void_p(None), ctypes.c_void_p(0x1000)
+    f = lib.symode_seeded_subsamples
+    assert f(0, 1, junk, 1, junk, null) == -3 and f(10, 0, junk, 1, junk, null) == -3        # n, m >= 1
+    assert f(10, 11, junk, 1, junk, null) == -3 and f(10, 5, junk, 0, junk, null) == -3      # m <= n, n_seeds >= 1
+    assert f(2 ** 31, 5, junk, 1, junk, null) == -3                                          # rows are int32
+    assert f(10, 5, null, 1, junk, null) == -2 and f(10, 5, junk, 1, null, null) == -2       # null pointers
+    assert f(10, 5, ctypes.c_void_p(0x1004), 1, junk, null) == -5                            # seeds are int64
+
+
 def test_argument_validation_of_the_round2_entries(lib):
     """Every entry added with ABI version 2 rejects bad sizes / null or misaligned pointers / short workspaces before it
     touches the GPU (codes: -1 unsupported, -2 null, -3 size, -4 workspace, -5 alignment)."""
