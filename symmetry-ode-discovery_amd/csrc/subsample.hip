@@ -2,7 +2,7 @@
 // n keys key(seed, row) -- a counter-based hash, so a seed's subsample depends on that seed alone (not on the other seeds
 // of the sweep, the world size or the device), rows ascending.  One workgroup per seed: three radix-select passes over the
 // 32-bit keys (LDS histograms of 11 + 11 + 10 bits) find the m-th smallest key T and how many keys equal to T still
-// belong to the subset; one ordered compaction pass (wave ballots + one LDS scan of the 16 wave totals per 1024 rows)
+// belong to the subset; one ordered compaction pass (eight consecutive rows per thread, two block scans per 8192 rows)
 // writes the rows with key < T, and the first ties in row order.  Keys are recomputed in every pass (13 integer
 // instructions) instead of being stored.
 // replaces: the first batch of DataLoader(train_dataset, batch_size=int(len * lbfgs_subsample), shuffle=True) per seed
@@ -78,35 +78,54 @@ __global__ __launch_bounds__(SB) void seeded_subsample_kernel(long n, long m, co
     }
     const unsigned T = prefix;                                            // the m-th smallest key; `need` keys equal to T belong
 
-    // ordered compaction: 1024 rows per step, positions from wave ballots + a scan of the 16 wave totals
+    // ordered compaction: RPT consecutive rows per thread and step (8192 rows per step), positions from a block scan of the
+    // per-thread counts (wave scan by shuffles + the 16 wave totals through LDS) -- first of the ties, which must be taken
+    // in row order, then of the chosen rows
+    constexpr int RPT = 8;
+    auto block_scan = [&](unsigned v, int buf, unsigned& total) -> unsigned {        // exclusive prefix of v over the workgroup
+        unsigned incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wave_tot[buf][wave] = incl;
+        __syncthreads();
+        unsigned before = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < SB / 64; ++w) {
+            const unsigned t = wave_tot[buf][w];
+            before += w < wave ? t : 0u;
+            total += t;
+        }
+        return before + incl - v;
+    };
     long base = 0, ties_before = 0;
-    for (long c0 = 0; c0 < n; c0 += SB) {
-        const long i = c0 + tid;
-        const unsigned k = i < n ? subsample_key(seed, (unsigned long long)i) : 0xFFFFFFFFu;
-        const bool in = i < n;
-        const bool eq = in && k == T;
-        const unsigned long long eq_mask = __ballot(eq);
-        if (lane == 0) wave_tot[0][wave] = (unsigned)__popcll(eq_mask);
-        __syncthreads();
-        long eq_before = ties_before;
-        unsigned eq_all = 0;
-        for (int w = 0; w < SB / 64; ++w) {
-            if (w < wave) eq_before += wave_tot[0][w];
-            eq_all += wave_tot[0][w];
+    for (long c0 = 0; c0 < n; c0 += (long)SB * RPT) {
+        const long i0 = c0 + (long)tid * RPT;
+        unsigned k[RPT];
+        unsigned n_eq = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            k[r] = i0 + r < n ? subsample_key(seed, (unsigned long long)(i0 + r)) : 0xFFFFFFFFu;
+            n_eq += (i0 + r < n && k[r] == T) ? 1u : 0u;
         }
-        eq_before += __popcll(eq_mask & ((1ull << lane) - 1ull));
-        const bool take = in && (k < T || (eq && eq_before < need));
-        const unsigned long long take_mask = __ballot(take);
-        if (lane == 0) wave_tot[1][wave] = (unsigned)__popcll(take_mask);
-        __syncthreads();
-        long pos = base;
-        unsigned take_all = 0;
-        for (int w = 0; w < SB / 64; ++w) {
-            if (w < wave) pos += wave_tot[1][w];
-            take_all += wave_tot[1][w];
+        unsigned eq_all, take_all;
+        long eq_before = ties_before + block_scan(n_eq, 0, eq_all);
+        bool take[RPT];
+        unsigned n_take = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const bool in = i0 + r < n, eq = in && k[r] == T;
+            take[r] = in && (k[r] < T || (eq && eq_before < need));
+            eq_before += eq ? 1 : 0;
+            n_take += take[r] ? 1u : 0u;
         }
-        pos += __popcll(take_mask & ((1ull << lane) - 1ull));
-        if (take) dst[pos] = (int)i;
+        long pos = base + block_scan(n_take, 1, take_all);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+            if (take[r]) dst[pos++] = (int)(i0 + r);
         base += take_all;
         ties_before += eq_all;
         __syncthreads();                                                  // wave_tot is rewritten by the next step
