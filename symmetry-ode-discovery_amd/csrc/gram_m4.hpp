@@ -46,7 +46,7 @@ struct GramM4Shape {
 };
 
 template <class Lib, int R = 3>
-__global__ __launch_bounds__(BLOCK) void aug_gram_m4_kernel(const float* __restrict__ x, const float* __restrict__ dx, long N,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void aug_gram_m4_kernel(const float* __restrict__ x, const float* __restrict__ dx, long N,
                                                             const int* __restrict__ idx, double* __restrict__ part) {
     using G = GramM4Shape<Lib>;
     constexpr int D = Lib::D, P = Lib::P, F = G::F, T = G::T, NT = G::NT, NV = (2 * D + 3) / 4, PS = 66, NW = BLOCK / WAVE;
