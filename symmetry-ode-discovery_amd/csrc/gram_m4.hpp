@@ -45,9 +45,11 @@ struct GramM4Shape {
     static constexpr bool OK = F > 12 && F <= 24;
 };
 
-// (waves_per_eu(4): 128 registers -- left alone the compiler takes 70 VGPRs + 64 AGPRs = 3 waves per SIMD; four measure +1.5 %)
+// (waves_per_eu(4) for the d = 2 polynomial libraries: 128 registers -- left alone the compiler takes 70 VGPRs + 64 AGPRs = 3
+//  waves per SIMD; four measure +1.5 %.  d = 3 and the sine / exp libraries would spill under that budget.)
 template <class Lib, int R = 3>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void aug_gram_m4_kernel(const float* __restrict__ x, const float* __restrict__ dx, long N,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((Lib::D == 2 && !Lib::SINE && !Lib::EXP) ? 4 : 1)))
+void aug_gram_m4_kernel(const float* __restrict__ x, const float* __restrict__ dx, long N,
                                                             const int* __restrict__ idx, double* __restrict__ part) {
     using G = GramM4Shape<Lib>;
     constexpr int D = Lib::D, P = Lib::P, F = G::F, T = G::T, NT = G::NT, NV = (2 * D + 3) / 4, PS = 66, NW = BLOCK / WAVE;
