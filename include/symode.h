@@ -185,7 +185,8 @@ int symode_rk4_traj(const double* x0, long n_traj, int d, int order, int flags, 
                     int subsample, float* x_out, float* dx_out, void* stream);
 
 /* Seed sweeps: idx_out (n_seeds, m) int32, rows ascending -- for every seed the m-subset of range(n) holding the m
- * smallest of n counter-based keys key(seed, row): a seed's subsample depends on that seed alone (not on the other seeds,
+ * smallest of n counter-based keys key(seed, row) (a 32-bit bijective mix of the row under two words derived from the
+ * seed): a seed's subsample depends on that seed alone (not on the other seeds,
  * the world size or the device).  seeds: n_seeds int64 on the device.  One workgroup per seed (radix select + ordered
  * compaction).  The table is what symode_aug_gram_gather takes.
  * replaces: the first batch of DataLoader(train_dataset, batch_size=int(len * lbfgs_subsample), shuffle=True) of each

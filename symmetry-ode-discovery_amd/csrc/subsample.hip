@@ -3,8 +3,8 @@
 // of the sweep, the world size or the device), rows ascending.  One workgroup per seed: three radix-select passes over the
 // 32-bit keys (LDS histograms of 11 + 11 + 10 bits) find the m-th smallest key T and how many keys equal to T still
 // belong to the subset; one ordered compaction pass (eight consecutive rows per thread, two block scans per 8192 rows)
-// writes the rows with key < T, and the first ties in row order.  Keys are recomputed in every pass (13 integer
-// instructions) instead of being stored.
+// writes the rows with key < T (and would take ties in row order: the present key has none).  Keys are recomputed in every
+// pass instead of being stored.
 // replaces: the first batch of DataLoader(train_dataset, batch_size=int(len * lbfgs_subsample), shuffle=True) per seed
 // (main.py:36-38) as an index table; the torch form it replaced (one generator launch per seed, a batched top-k and a
 // sort) took 1.1-1.2 ms for 64 seeds of 10^5 rows, three quarters of the sequential-threshold sweep's wall time.
@@ -16,14 +16,28 @@ namespace {
 
 constexpr int SB = 1024;                                  // threads per workgroup: 16 waves
 
-__device__ __forceinline__ unsigned subsample_key(unsigned long long seed, unsigned long long row) {
-    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + row * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+// key(seed, row) = fmix32((row ^ a) * 0x9E3779B1 + b), (a, b) = the two halves of a 64-bit mix of the seed: three 32-bit
+// multiplies per row (the kernel recomputes every key in each of its four passes; a 64-bit mixer per row -- twelve
+// quarter-rate multiplies -- made the hash most of its time: 103 us for 64 seeds of 10^5 rows).  Every step is a bijection
+// of the 32-bit word, so for n <= 2^32 rows no two rows of a seed share a key.
+__device__ __forceinline__ unsigned long long seed_words(unsigned long long seed) {
+    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
     z ^= z >> 30;
     z *= 0xBF58476D1CE4E5B9ull;
     z ^= z >> 27;
     z *= 0x94D049BB133111EBull;
     z ^= z >> 31;
-    return (unsigned)(z >> 32);
+    return z;
+}
+
+__device__ __forceinline__ unsigned subsample_key(unsigned a, unsigned b, unsigned row) {
+    unsigned h = (row ^ a) * 0x9E3779B1u + b;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 
 __global__ __launch_bounds__(SB) void seeded_subsample_kernel(long n, long m, const long long* __restrict__ seeds,
@@ -33,7 +47,8 @@ __global__ __launch_bounds__(SB) void seeded_subsample_kernel(long n, long m, co
     __shared__ unsigned sel_bin;
     __shared__ long sel_need;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long seed = (unsigned long long)seeds[blockIdx.x];
+    const unsigned long long sw = seed_words((unsigned long long)seeds[blockIdx.x]);
+    const unsigned ka = (unsigned)sw, kb = (unsigned)(sw >> 32);
     int* dst = out + (long)blockIdx.x * m;
 
     // radix select: after pass p the top bits of T are known (`prefix`), `need` = rank of T among the keys that share them
@@ -45,7 +60,7 @@ __global__ __launch_bounds__(SB) void seeded_subsample_kernel(long n, long m, co
         for (int b = tid; b < 2048; b += SB) hist[b] = 0;
         __syncthreads();
         for (long i = tid; i < n; i += SB) {
-            const unsigned k = subsample_key(seed, (unsigned long long)i);
+            const unsigned k = subsample_key(ka, kb, (unsigned)i);
             if (hi >= 32 || (k >> hi) == (prefix >> hi)) atomicAdd(&hist[(k >> sh) & (nb - 1)], 1u);
         }
         __syncthreads();
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(SB) void seeded_subsample_kernel(long n, long m, co
         unsigned n_eq = 0;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            k[r] = i0 + r < n ? subsample_key(seed, (unsigned long long)(i0 + r)) : 0xFFFFFFFFu;
+            k[r] = i0 + r < n ? subsample_key(ka, kb, (unsigned)(i0 + r)) : 0xFFFFFFFFu;
             n_eq += (i0 + r < n && k[r] == T) ? 1u : 0u;
         }
         unsigned eq_all, take_all;
