@@ -18,6 +18,8 @@
 
 namespace symode {
 
+constexpr int GRAM_RING = 3;      // chunks of (x, dx) in flight per lane; 2, 3 and 4 measure alike, the two-chunk LOOP it replaced 8 % slower
+
 template <class Lib>
 struct GramValuShape {
     static constexpr int F = Lib::P + Lib::D;
@@ -59,34 +61,35 @@ __global__ __launch_bounds__(BLOCK) void aug_gram_valu_kernel(const float* __res
     };
     const long tid = (long)blockIdx.x * BLOCK + threadIdx.x, nthreads = (long)gridDim.x * BLOCK;
     if (is == nullptr && vec) {
+        // register ring: GRAM_RING chunks of x and dx in flight per lane, a slot refilled as soon as it is consumed
+        // (points.hpp, chunk_ring) -- at two waves per SIMD (the 78 fp64 sums) the wave's own run-ahead is what hides HBM:
+        // order 3, 2^26 points 275 -> 253 us, 1024 x 125 000 495 -> 464 us, order 2 + exp 258 -> 236 us (same box)
         const long nchunks = N / PPT;
-        long c = tid;
-        for (; c + nthreads < nchunks; c += 2 * nthreads) {
-            float4 ax[NV], ay[NV], bx[NV], by[NV];
-            load_chunk_raw<D, true>(xs, c, ax);
-            load_chunk_raw<D, true>(ys, c, ay);
-            load_chunk_raw<D, true>(xs, c + nthreads, bx);
-            load_chunk_raw<D, true>(ys, c + nthreads, by);
-            float xa[PPT][D], ya[PPT][D], xb[PPT][D], yb[PPT][D];
-            unpack_chunk<D>(ax, xa);
-            unpack_chunk<D>(ay, ya);
-            unpack_chunk<D>(bx, xb);
-            unpack_chunk<D>(by, yb);
+        chunk_ring<GRAM_RING, 2 * NV>(
+            nchunks, tid, nthreads,
+            [&](long q, float4 (&slot)[2 * NV]) {
+                float4 tx[NV], ty[NV];
+                load_chunk_raw<D, true>(xs, q, tx);
+                load_chunk_raw<D, true>(ys, q, ty);
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) one(xa[i], ya[i]);
+                for (int i = 0; i < NV; ++i) {
+                    slot[i] = tx[i];
+                    slot[NV + i] = ty[i];
+                }
+            },
+            [&](long, const float4 (&slot)[2 * NV]) {
+                float4 tx[NV], ty[NV];
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) one(xb[i], yb[i]);
-        }
-        if (c < nchunks) {
-            float4 ax[NV], ay[NV];
-            load_chunk_raw<D, true>(xs, c, ax);
-            load_chunk_raw<D, true>(ys, c, ay);
-            float xa[PPT][D], ya[PPT][D];
-            unpack_chunk<D>(ax, xa);
-            unpack_chunk<D>(ay, ya);
+                for (int i = 0; i < NV; ++i) {
+                    tx[i] = slot[i];
+                    ty[i] = slot[NV + i];
+                }
+                float xa[PPT][D], ya[PPT][D];
+                unpack_chunk<D>(tx, xa);
+                unpack_chunk<D>(ty, ya);
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) one(xa[i], ya[i]);
-        }
+                for (int i = 0; i < PPT; ++i) one(xa[i], ya[i]);
+            });
         const long n = nchunks * PPT + tid;
         if (n < N) {
             float xp[D], yp[D];
