@@ -873,3 +873,26 @@ def test_seeded_subsamples_large_table_and_inclusion_statistics(eng):
     overlap = (member @ member.T).cpu().numpy()                              # pairs of seeds: hypergeometric, mean 5000, sd 35
     off = overlap[~np.eye(64, dtype=bool)]
     assert abs(off.mean() - 5000.0) < 20.0 and np.abs(off - 5000.0).max() < 250.0, (off.mean(), off.min(), off.max())
+
+
+def test_index_table_is_checked_once_per_table_and_again_after_a_change(eng):
+    """aug_gram_gather trusts a table it has checked (the check is a reduction + a sync, dearer than the kernel at config[3]'s
+    size) -- by tensor object and in-place version: an out-of-range row is refused on the first call, and a table spoiled in
+    place AFTER a good call is refused as well."""
+    import symode_amd
+    x, dx = torch.randn(1000, 2).cuda(), torch.randn(1000, 2).cuda()
+    idx = torch.arange(0, 1000, 2, dtype=torch.int32).repeat(3, 1).cuda()
+    bad = idx.clone()
+    bad[1, 7] = 1000
+    with pytest.raises(symode_amd.engine.SymodeError):
+        eng.aug_gram_gather(x, dx, bad, 3)
+    a = eng.aug_gram_gather(x, dx, idx, 3)
+    b = eng.aug_gram_gather(x, dx, idx, 3)                       # the remembered table
+    assert torch.equal(a, b)
+    idx[2, 0] = -1
+    with pytest.raises(symode_amd.engine.SymodeError):
+        eng.aug_gram_gather(x, dx, idx, 3)
+    other = torch.arange(1, 1000, 2, dtype=torch.int32).repeat(3, 1).cuda()
+    c = eng.aug_gram_gather(x, dx, other, 3)
+    A = torch.cat([eng.theta(x[1::2], 3), dx[1::2]], dim=1).double()
+    assert torch.allclose(c[0], A.T @ A, rtol=1e-12, atol=0)
