@@ -235,26 +235,35 @@ __device__ __forceinline__ void gram_split_body(const float* __restrict__ xs, co
         gram_run_accumulate<F, G::NPAIR, PART * NE, NE>(f, acc, std::make_integer_sequence<int, NE>{});
     };
     if (vec) {
-        // one chunk per step, the next one requested before this one's arithmetic (the run's NE fp64 sums and the F fp64
-        // features leave no room for more in flight: 2 waves per SIMD)
+        // register ring of two chunks per lane, a slot refilled as soon as it is consumed (the run's NE fp64 sums and the F
+        // fp64 features leave no room for more in flight: 2 waves per SIMD); plain loads: the sibling runs read the same
+        // lines from L2
         const long nchunks = N / PPT;
-        long c = tid;
-        float4 ax[NV], ay[NV];
-        if (c < nchunks) {
-            load_chunk_raw<D, false>(xs, c, ax);               // plain loads: the sibling runs read the same lines from L2
-            load_chunk_raw<D, false>(ys, c, ay);
-        }
-        for (; c < nchunks; c += nthreads) {
-            float xa[PPT][D], ya[PPT][D];
-            unpack_chunk<D>(ax, xa);
-            unpack_chunk<D>(ay, ya);
-            if (c + nthreads < nchunks) {
-                load_chunk_raw<D, false>(xs, c + nthreads, ax);
-                load_chunk_raw<D, false>(ys, c + nthreads, ay);
-            }
+        chunk_ring<2, 2 * NV>(
+            nchunks, tid, nthreads,
+            [&](long q, float4 (&slot)[2 * NV]) {
+                float4 tx[NV], ty[NV];
+                load_chunk_raw<D, false>(xs, q, tx);
+                load_chunk_raw<D, false>(ys, q, ty);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    slot[i] = tx[i];
+                    slot[NV + i] = ty[i];
+                }
+            },
+            [&](long, const float4 (&slot)[2 * NV]) {
+                float4 tx[NV], ty[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    tx[i] = slot[i];
+                    ty[i] = slot[NV + i];
+                }
+                float xa[PPT][D], ya[PPT][D];
+                unpack_chunk<D>(tx, xa);
+                unpack_chunk<D>(ty, ya);
 #pragma unroll 1
-            for (int i = 0; i < PPT; ++i) one(xa[i], ya[i]);
-        }
+                for (int i = 0; i < PPT; ++i) one(xa[i], ya[i]);
+            });
         const long n = nchunks * PPT + tid;
         if (n < N) {
             float xp[D], yp[D];
