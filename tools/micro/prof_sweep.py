@@ -1,6 +1,6 @@
 import cProfile, os, pstats, sys, time
 import torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import symode_amd
 from symode_amd import data
 from symode_amd.batched import BatchedClosure
