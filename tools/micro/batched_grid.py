@@ -1,7 +1,7 @@
 """Batched closure kernel time vs the workgroup budget (SYMODE_MAX_GRID, read once per process)."""
 import os, sys
 import torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import symode_amd
 eng = symode_amd.get_engine()
 shapes = [(16, 125000, 3), (64, 50000, 3), (64, 125000, 3), (256, 50000, 3), (512, 125000, 3), (1024, 125000, 5), (2048, 20000, 3)]

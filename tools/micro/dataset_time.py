@@ -1,6 +1,6 @@
 """First-run cost of the reference's data recipes (RK4 + noise + GP smoothing), by phase (cProfile)."""
 import cProfile, io, os, pstats, sys, tempfile, time, contextlib
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from symode_amd.parser_utils import get_args
 from symode_amd.dataset import get_dataset

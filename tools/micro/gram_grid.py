@@ -2,7 +2,7 @@
 (SYMODE_GRAM_VALU_GRID / SYMODE_GRAM_GRID / SYMODE_MAX_GRID: read once per process -> one process per setting)."""
 import os, sys
 import torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import symode_amd
 eng = symode_amd.get_engine()
 

@@ -1,7 +1,7 @@
 """symode_lbfgs_update: kernel time vs the number of stored curvature pairs m (S problems, n parameters, history 100)."""
 import os, sys, types
 import torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import symode_amd
 from symode_amd.sweep import BatchedLBFGS
 eng = symode_amd.get_engine()

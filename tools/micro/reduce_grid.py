@@ -2,8 +2,8 @@
 value of SYMODE_REDUCE_GRID (workgroup cap, read once per process): us per launch, 20 launches replayed from a graph."""
 import os, sys
 import torch
-sys.path.insert(0, os.getcwd())
-sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools"))
 import symode_amd
 from kbench import stream_op
 eng = symode_amd.get_engine()

@@ -1,7 +1,7 @@
 """Single-problem reduction kernels vs N and the small-grid cap (SYMODE_SMALL_GRID; engine.reload_env() after every change)."""
 import os, sys
 import torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import symode_amd
 eng = symode_amd.get_engine()
 order = int(os.environ.get("ORDER", "3"))

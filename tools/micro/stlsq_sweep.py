@@ -1,7 +1,7 @@
 """BASELINE config[3] shape: selkov 10 x 10000 x 2, 64 seeds x 50 % subsample, order 3: SeedSweepSTLSQ wall time split."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import symode_amd
 from symode_amd import data
 from symode_amd.sweep import SeedSweepSTLSQ
