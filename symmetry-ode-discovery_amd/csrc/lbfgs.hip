@@ -158,13 +158,28 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
     extern __shared__ float staged[];                        // STAGED: pad [n] | Y [H][n] | S [H][n] | ro [H] | 256 floats of padding
     const long s = blockIdx.x;
     const int lane = threadIdx.x;
+    // Every per-problem scalar and state vector of this launch is requested HERE, in one batch, before the first of them is
+    // waited for: the state was written by other launches (the closure's last workgroup, the previous update -- other
+    // XCDs' L2), so each dependent trip costs ~1 us on a lone wave, and read where they are used (behind the early
+    // returns and the stores of g and loss) they queued up as four to five trips -- most of the launch's fixed cost.
+    // Reading them for a problem that turns out to have stopped is harmless.
+    const unsigned char act_in = BEGIN ? (unsigned char)1 : act[s];
+    const float t_in = t[s], hd_in = h_diag[s], prev_loss_in = prev_loss[s];
+    const long ni_in = n_iter[s], count_in = count[s], head_in = head[s];
+    float d_in[LB_MAXC], pg_in[LB_MAXC];
+#pragma unroll
+    for (int c = 0; c < LB_MAXC; ++c) {
+        const int i = lane + WAVE * c;
+        d_in[c] = i < n ? d[s * n + i] : 0.0f;
+        pg_in[c] = i < n ? prev_g[s * n + i] : 0.0f;
+    }
     if constexpr (BEGIN) {
         if (hook.done != nullptr && __builtin_amdgcn_readfirstlane((int)hook.done[s])) {   // finished by the epoch logic
             if (lane == 0) act[s] = 0;
             return;
         }
     } else {
-        if (!__builtin_amdgcn_readfirstlane((int)act[s])) return;   // wave-uniform: this problem stopped earlier
+        if (!__builtin_amdgcn_readfirstlane((int)act_in)) return;   // wave-uniform: this problem stopped earlier
     }
     float* const ldsY = staged + n;                          // (a row of padding in front: the loops prefetch row -1)
     float* const ldsS = ldsY + H * n;
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
     float gv[LB_MAXC], q[LB_MAXC];
     float loss_s;
     if constexpr (ACCEPT || BEGIN) {
-        const float tt = BEGIN ? 0.0f : t[s];
+        const float tt = BEGIN ? 0.0f : t_in;
         float nl = acc.pair ? fmaf(acc.w_pair, acc.new_loss[2 * s + 1], acc.new_loss[2 * s]) : acc.new_loss[s];
         float gmax = 0.0f, dmax = 0.0f, p_l1 = 0.0f;
         if (map.q != nullptr) {                              // d/dXi (d p) -> LDS; each lane then forms its parameter's gradient
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
                 }
                 g[s * n + i] = v;
                 gv[c] = v;
-                const float av = fabsf(v), ad = BEGIN ? 1.0f : fabsf(d[s * n + i] * tt);
+                const float av = fabsf(v), ad = BEGIN ? 1.0f : fabsf(d_in[c] * tt);
                 gmax = (av != av || gmax != gmax) ? __builtin_nanf("") : fmaxf(gmax, av);
                 dmax = (ad != ad || dmax != dmax) ? __builtin_nanf("") : fmaxf(dmax, ad);
             }
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
         // i.e. a NaN gradient does NOT stop the step (the parameters go to NaN and the epoch logic's NaN guard ends the
         // run, train.py:697); ACCEPT: its three tests after the re-evaluation.
         const bool stop = BEGIN ? (gmax <= acc.tol_grad)
-                                : ((gmax <= acc.tol_grad) || (dmax <= tol_change) || (fabsf(nl - prev_loss[s]) < tol_change));
+                                : ((gmax <= acc.tol_grad) || (dmax <= tol_change) || (fabsf(nl - prev_loss_in) < tol_change));
         if (lane == 0) loss[s] = nl;
         if (__builtin_amdgcn_readfirstlane((int)stop)) {
             if (lane == 0) act[s] = 0;
@@ -236,23 +251,23 @@ __global__ __launch_bounds__(WAVE) void lbfgs_update_kernel(float* __restrict__ 
         }
         loss_s = loss[s];
     }
-    const long ni = (long)__builtin_amdgcn_readfirstlane((int)n_iter[s]) + 1;      // (scalars: uniform loop bounds below)
+    const long ni = (long)__builtin_amdgcn_readfirstlane((int)ni_in) + 1;          // (scalars: uniform loop bounds below)
     const bool first = ni == 1;
     float* Y = old_dirs + s * (long)H * n;
     float* Sx = old_stps + s * (long)H * n;
     float* R = ro + s * (long)H;
-    int m = first ? 0 : __builtin_amdgcn_readfirstlane((int)count[s]);
-    int h0 = first ? 0 : __builtin_amdgcn_readfirstlane((int)head[s]);
-    float hd = first ? 1.0f : __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h_diag[s])));
+    int m = first ? 0 : __builtin_amdgcn_readfirstlane((int)count_in);
+    int h0 = first ? 0 : __builtin_amdgcn_readfirstlane((int)head_in);
+    float hd = first ? 1.0f : __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hd_in)));
     bool fresh = false;                                      // a pair was stored in this launch (logical slot m - 1)
     if (!first) {                                            // "do lbfgs update (update memory)"
-        const float told = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t[s])));
+        const float told = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t_in)));
         float y[LB_MAXC], sv[LB_MAXC], p_ys = 0.0f, p_yy = 0.0f;
 #pragma unroll
         for (int c = 0; c < LB_MAXC; ++c) {
             const int i = lane + WAVE * c;
-            y[c] = i < n ? gv[c] - prev_g[s * n + i] : 0.0f;
-            sv[c] = i < n ? d[s * n + i] * told : 0.0f;
+            y[c] = i < n ? gv[c] - pg_in[c] : 0.0f;
+            sv[c] = i < n ? d_in[c] * told : 0.0f;
             p_ys = fmaf(y[c], sv[c], p_ys);
             p_yy = fmaf(y[c], y[c], p_yy);
         }
