@@ -219,8 +219,9 @@ int symode_loss_grad(const float* x, const float* dx, long n_problems, long n, i
     // (SYMODE_SMALL_GRID overrides the cap for tuning runs; 0 = no cap)
     if (n_problems == 1) {
         // (order 4-5 libraries are as arithmetic-heavy as the regulariser closures: 64 M points at order 5, 240 us at 256
-        //  workgroups, 184 at 512 -- profiles/r03_closure_ab.txt)
-        const int cap = small_grid_cap(n, ops->d * ops->p > 32);
+        //  workgroups, 184 at 512 -- profiles/r03_closure_ab.txt; order 4 (d p = 30): 191 against 176 us; order 3 (20) is
+        //  best at 256: 161 against 169)
+        const int cap = small_grid_cap(n, ops->d * ops->p > 24);
         if (cap > 0 && gx > cap) gx = cap;
     }
     return (int)ops->loss_grad(x, dx, n_problems, n, xi, mask, inv_count, loss_out, grad_out, (double*)workspace, gx,
