@@ -276,7 +276,10 @@ int symode_symreg_reversed_batched(const float* x, const float* gx_, const float
     SYMODE_CHECK_WS(n_problems, n);
     int gx = grid_x_for(n, n_problems, ppt_for(d), 512);
     if (n_problems == 1) {
-        const int cap = small_grid_cap(n, true);
+        // (32 B/point: the small libraries stream best from ONE workgroup per CU like the other reductions -- order 3 at 2^26
+        //  points 314 us = 0.855 of HBM on 256 workgroups against 338 on 512; order 4-5 want the second one: 340 against 374 us)
+        int cap = small_grid_cap(n, true);
+        if (cap > 256 && ops->d * ops->p <= 24 && knobs().small_grid < 0) cap = 256;
         if (cap > 0 && gx > cap) gx = cap;
     }
     return (int)ops->symreg_reversed(x, nullptr, gx_, jgx, n_g, n_problems, n, xi, mask, inv_count, 1.0f, loss_out, grad_out,
