@@ -1,5 +1,6 @@
-// Augmented Gram matrix for 12 < F = p + d <= 24 (order 4-5 at d = 2, the d = 3 libraries up to 20 terms) on
-// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction.
+// Augmented Gram matrix  S = [Theta | dx]^T [Theta | dx]  for 12 < F = p + d <= 24 (order 4-5 at d = 2, the d = 3 libraries
+// up to 20 terms) on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction.  (What the host solves from
+// S replaces torch.linalg.lstsq on the ridge-augmented / block-diagonal system of sindy.py:250-315.)
 //
 // Why this shape.  fp64 products run on one set of units whoever issues them (tools/micro/mfma_f64_probe,
 // profiles/r03_mfma_f64_probe.txt: v_fma_f64 33.9 T multiply-adds/s, 4x4x4 MFMA 33.9-34.4, both interleaved 36.9, and
