@@ -340,7 +340,9 @@ int symode_vjp(const float* x, const float* g, long n, int d, int order, int fla
     SYMODE_CHECK_WS(1, n);
     // register ring of 3 chunks per lane: one workgroup per CU streams best from 4 M points up (round 3,
     // profiles/r03_stream_ab.txt: 64 M points 262 us at 256 workgroups against 321 at 1024; without grad_x 152 against 188)
-    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 64, 128, 256, 256);
+    // (order 5, d p = 42: the second workgroup per CU pays from 8 M points -- 2^26 points 316 -> 295 us; orders 3-4 lose 8-11 % on it)
+    const bool heavy = ops->d * ops->p > 32 && grad_x != nullptr;        // (without grad_x one per CU stays best: 163 against 175 us)
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 64, 128, heavy ? 512 : 256, heavy ? 512 : 256);
     return (int)ops->vjp(x, g, n, xi, mask, grad_x, grad_xi, (double*)workspace, gx, (hipStream_t)stream);
 }
 
@@ -366,7 +368,11 @@ int symode_jvp_vjp(const float* x, const float* v, const float* g_out, const flo
         misaligned(mask, 4) || misaligned(grad_x, 4) || misaligned(grad_v, 4) || misaligned(grad_xi, 4))
         return SYMODE_E_ALIGN;
     SYMODE_CHECK_WS(1, n);
-    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, 256, 256);      // ring of 3: r03_stream_ab.txt
+    // ring of 3: r03_stream_ab.txt.  Order 5 (d p = 42) wants more than one workgroup per CU: 2^26 points, us at 256 / 512 /
+    // 768 workgroups 693 / 652 / 646 on one box, 727 / - / 672-694 on another; 8 M points 94 -> 82 us at 512.  Orders 3-4
+    // stay at one per CU (768 won on one box, 531 against 546 us, and lost on the next, 586-602 against 545-567)
+    const bool heavy = ops->d * ops->p > 32;
+    const int gx = single_problem_grid(grid_x_for(n, 1, ppt_for(d)), n, 128, 256, heavy ? 512 : 256, heavy ? 768 : 256);
     return (int)ops->jvp_vjp(x, v, g_out, g_jv, n, xi, mask, grad_x, grad_v, grad_xi, (double*)workspace, gx,
                              (hipStream_t)stream);
 }
